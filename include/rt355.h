@@ -1,0 +1,145 @@
+/* rt355.h — C-ABI of the MI355X device path (librt355.so).
+ *
+ * The reference has no FFI: its "operator API" is the Kernel/Buffer call sequence that
+ * Renderer issues (reference: src/renderer.cpp:64-94 RayTrace, :142-209 InitBuffers,
+ * :211-263 InitWavefrontKernels, :289-301 FocusCamera, :126-140 ComputeEnergy) plus the
+ * POD arrays of src/common.h.  Each entry point below replaces the cited piece of that
+ * sequence; INTEGRATION.md shows the Renderer-side binding.
+ *
+ * Conventions: every function returns 0 on success and a negative RT_E_* code on
+ * failure; rt_last_error() returns a thread-local message (the reference aborts through
+ * FatalError(), template/template.cpp:949-962 — this library never aborts).  Host
+ * pointers are copied during the call and never retained (the reference's Buffer keeps
+ * a non-owning alias and copies in CopyToDevice(), template.cpp:1133-1137).  A context
+ * is bound to one GPU and is not re-entrant: one host thread (or process) per GPU.
+ * There is NO CPU fallback: without a HIP device rt_create() fails.
+ */
+#ifndef RT355_H
+#define RT355_H
+#include "rt355_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK            0
+#define RT_E_INVALID    (-1)   /* bad argument / call order                       */
+#define RT_E_DEVICE     (-2)   /* HIP error (message in rt_last_error)            */
+#define RT_E_NOMEM      (-3)
+#define RT_E_UNSUPPORTED (-4)
+
+/* Kernel variants — the reference's prepended #defines (renderer.h:6-19, renderer.cpp:213-215). */
+#define RT_SHADING_SIMPLE       0   /* SHADING_SIMPLE ("Kajiya")  */
+#define RT_SHADING_NEE          1   /* SHADING_NEE (default)      */
+#define RT_SAMPLING_HEMISPHERE  0   /* SAMPLING_HEMISPHERE        */
+#define RT_SAMPLING_COSINE      1   /* SAMPLING_COSINE (default)  */
+#define RT_ACCEL_BVH2           0   /* USE_BVH2 (default)         */
+#define RT_ACCEL_BVH4           1   /* USE_BVH4                   */
+
+typedef struct RtCtx RtCtx;
+
+/* Replaces the compile-time macros of src/constants.h:3-7,28-31 and the ImGuiData
+ * variant selection (renderer.h:23-36) with run-time values. */
+typedef struct RtConfig {
+    int32_t width, height;      /* SCRWIDTH, SCRHEIGHT                                        */
+    int32_t y0, y1;             /* row band [y0,y1) this context renders; 0,height = all rows  */
+    int32_t max_bounces;        /* MAX_BOUNCES host loop count (7); must be 1..RT_MAX_BOUNCES  */
+    int32_t shading, sampling, accel;
+    int32_t russian_roulette;   /* RUSSIAN_ROULETTE                                           */
+    int32_t filter_fireflies;   /* FILTER_FIREFLIES                                           */
+    int32_t device;             /* HIP device ordinal                                         */
+    int32_t extend_variant;     /* 0 = default kernel; other values select tuning variants     */
+    int32_t profile;            /* 1 = bracket every stage launch with HIP events              */
+    int32_t reserved[3];
+} RtConfig;
+
+/* Device-side work counters (per-kernel-family totals since the last rt_reset_counters).
+ * They define the algorithmic bytes of SURVEY.md §8(d). */
+typedef struct RtCounters {
+    uint64_t extend_rays, extend_tlas_visits, extend_inst_visits, extend_node_visits, extend_prim_tests;
+    uint64_t connect_rays, connect_tlas_visits, connect_inst_visits, connect_node_visits, connect_prim_tests;
+    uint64_t primary_rays;       /* pixels generated                     */
+    uint64_t shadow_rays;        /* shadow rays appended by shade        */
+    uint64_t frames;
+} RtCounters;
+
+/* Accumulated stage times in milliseconds (HIP events on the context's stream) and
+ * launch counts; only filled when RtConfig.profile != 0. */
+typedef struct RtStageTimes {
+    double  generate_ms, extend_ms, shade_ms, compact_ms, connect_ms, accumulate_ms;
+    int64_t generate_launches, extend_launches, shade_launches, compact_launches, connect_launches, accumulate_launches;
+} RtStageTimes;
+
+const char* rt_last_error(void);
+int rt_device_count(void);
+
+/* new Buffer(...) x11 + new Kernel(...) x6 (renderer.cpp:145-157, :218-223). */
+int rt_create(const RtConfig* cfg, RtCtx** out);
+int rt_destroy(RtCtx* ctx);
+
+/* primBuffer/matBuffer/texBuffer/lightBuffer/bvhNodeBuffer/bvhIdxBuffer/tlasNodeBuffer/
+ * blasNodeBuffer ->CopyToDevice() (renderer.cpp:160-208).  bvhNodes is RtBVHNode2[nNodes]
+ * for RT_ACCEL_BVH2 and RtBVHNode4[nNodes] for RT_ACCEL_BVH4, uploaded unchanged. */
+int rt_upload_scene(RtCtx* ctx,
+                    const RtPrimitive* prims, int32_t nPrims,
+                    const RtMaterial* mats, int32_t nMats,
+                    const RtFloat4* textures, int32_t nTexels,
+                    const uint32_t* lights, int32_t nLights,
+                    const void* bvhNodes, int32_t nNodes,
+                    const uint32_t* primIdx, int32_t nIdx,
+                    const RtTLASNode* tlas, int32_t nTlas,
+                    const RtBVHInstance* blas, int32_t nBlas);
+
+/* seedBuffer (renderer.cpp:195-196,200).  rt_set_seeds takes the band's slice
+ * (one uint per band pixel); rt_seed_default fills seeds[i] with the (firstPixel+i+1)-th
+ * xorshift32 output from 0x12345678 like the reference's host loop. */
+int rt_set_seeds(RtCtx* ctx, const uint32_t* seeds, int64_t n);
+int rt_seed_default(RtCtx* ctx);
+int rt_get_seeds(RtCtx* ctx, uint32_t* out, int64_t n);
+
+/* Optional: render into a caller-owned device accumulator float4[width*height]
+ * (e.g. a torch tensor, so that torch.distributed can reduce it). NULL = own buffer. */
+int rt_bind_accum(RtCtx* ctx, void* devicePtr);
+void* rt_accum_device_ptr(RtCtx* ctx);
+void* rt_stream(RtCtx* ctx);
+
+/* resetKernel->Run(PIXELS) (renderer.cpp:41-46): clears this context's band. */
+int rt_reset(RtCtx* ctx);
+
+/* Renderer::RayTrace() x frames (renderer.cpp:64-94): generate, then max_bounces x
+ * (extend, shade[, connect when RR is off]), then connect.  Uses settings->antiAliasing
+ * and settings->renderBVH; asynchronous on the context's stream. */
+int rt_render(RtCtx* ctx, const RtCamera* cam, const RtSettings* settings, int32_t frames);
+int rt_synchronize(RtCtx* ctx);
+
+/* focusKernel->Run(1) + settingsBuffer->CopyFromDevice() (renderer.cpp:289-301). */
+int rt_focus(RtCtx* ctx, int32_t x, int32_t y, const RtCamera* cam, float* t);
+
+/* accumBuffer->CopyFromDevice() (renderer.cpp:128): full frame float4[width*height]. */
+int rt_read_accum(RtCtx* ctx, RtFloat4* out);
+int rt_read_counters(RtCtx* ctx, RtCounters* out);
+int rt_reset_counters(RtCtx* ctx);
+int rt_read_stage_times(RtCtx* ctx, RtStageTimes* out);
+int rt_reset_stage_times(RtCtx* ctx);
+
+/* ---- stage-level entry points (one kernel of the reference each), used by the parity
+ * tests to feed identical inputs to one stage at a time ------------------------------ */
+int rt_stage_begin_frame(RtCtx* ctx);                                           /* renderer.cpp:66-69   */
+int rt_stage_generate(RtCtx* ctx, const RtCamera* cam, const RtSettings* s);    /* wavefront.cl:14-34   */
+int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH);             /* wavefront.cl:35-75   */
+int rt_stage_shade(RtCtx* ctx, int32_t bounce);                                 /* wavefront.cl:76-142  */
+int rt_stage_connect(RtCtx* ctx, int32_t firstBounce, int32_t lastBounce);      /* wavefront.cl:144-201 */
+/* Ray queue of `bounce` as reference-layout Ray structs (I and N as extend leaves them). */
+int rt_debug_get_rays(RtCtx* ctx, int32_t bounce, RtRay* out, int32_t capacity, int32_t* n);
+int rt_debug_set_rays(RtCtx* ctx, int32_t bounce, const RtRay* in, int32_t n);
+/* Shadow rays appended by shade() of bounces [firstBounce,lastBounce], in queue order:
+ * origin = I + L*EPSILON (xyz), tmax = dist - 2*EPSILON, dir = L (xyz), pixel index and the
+ * radiance the ray carries if unoccluded. */
+typedef struct RtShadowRecord { float ox, oy, oz, tmax; float lx, ly, lz; int32_t pixelIdx; RtFloat4 radiance; } RtShadowRecord;
+int rt_debug_get_shadow(RtCtx* ctx, int32_t firstBounce, int32_t lastBounce, RtShadowRecord* out, int32_t capacity, int32_t* n);
+int rt_debug_get_steps(RtCtx* ctx, int32_t* out, int32_t capacity, int32_t* n);  /* per-ray `steps` of the last extend */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT355_H */

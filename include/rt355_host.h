@@ -1,0 +1,73 @@
+/* rt355_host.h — C-ABI of the host-side producers (librt355_host.so): the Scene primitive /
+ * material factory, the BVH2 / SBVH / BVH4 / TLAS builders, the camera maths and a Renderer
+ * mirror.  These wrap the C++ classes of magr_ray_tracer_amd/host/rt_host.h, which mirror the
+ * reference's Scene (src/scene.h:5-34), BVH2/BVH4 (src/bvh.h:4-56), TLAS (src/tlas.h:2-12),
+ * CameraManager (src/camera.h:7-122) and Renderer (src/renderer.h:44-120).
+ * All functions return 0 on success, negative on failure (rth_last_error() has the text).
+ */
+#ifndef RT355_HOST_H
+#define RT355_HOST_H
+#include "rt355_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct RthScene RthScene;
+typedef struct RthRenderer RthRenderer;
+
+const char* rth_last_error(void);
+
+/* Scene::Scene / ~Scene (scene.cpp:8-10,74) */
+RthScene* rth_scene_create(void);
+void      rth_scene_destroy(RthScene* s);
+/* Scene::AddMaterial (scene.cpp:84-100): pushes a zeroed material (texIdx -1), then copies the
+ * fields of *init if given; returns the material index. */
+int rth_add_material(RthScene* s, const char* name, const RtMaterial* init);
+/* Scene::LoadTexture minus the file read (scene.cpp:244-256): appends texels, adds a material. */
+int rth_add_texture(RthScene* s, const char* name, const RtFloat4* texels, int width, int height);
+int rth_add_sphere(RthScene* s, const float pos[3], float radius, const char* material);       /* scene.cpp:125-138 */
+int rth_add_plane(RthScene* s, const float N[3], float d, const char* material);               /* scene.cpp:140-150 */
+int rth_add_triangle(RthScene* s, const float v0[3], const float v1[3], const float v2[3],
+                     const float uv0[2], const float uv1[2], const float uv2[2], const char* material, int flipNormal); /* scene.cpp:158-176 */
+int rth_add_quad(RthScene* s, const float v0[3], const float v1[3], const float v2[3], const float v3[3],
+                 const char* material, int flipNormal);                                       /* scene.cpp:152-156, default uvs */
+/* n x AddTriangle; verts is n*9 floats (v0,v1,v2), uvs n*6 floats or NULL (all zero). */
+int rth_add_triangles(RthScene* s, const float* verts, const float* uvs, int n, const char* material, int flipNormal);
+/* BVH2::BuildBLAS(true, startIdx) with bvh2->alpha = alpha (bvh.cpp:46-82). */
+int rth_build_blas(RthScene* s, int startIdx, float alpha);
+int rth_build_bvh4(RthScene* s);            /* new BVH4(*bvh2) (scene.cpp:71)                    */
+int rth_build_tlas(RthScene* s);            /* new TLAS(*bvh2); Build() (renderer.cpp:12-13)     */
+int rth_set_instance_transform(RthScene* s, int blas, const float invT[16]); /* scene.cpp:82 (commented out there) */
+
+/* Borrowed views of the arrays (valid until the scene changes). */
+const RtPrimitive*   rth_primitives(RthScene* s, int* n);
+const RtMaterial*    rth_materials(RthScene* s, int* n);
+const RtFloat4*      rth_textures(RthScene* s, int* n);
+const uint32_t*      rth_lights(RthScene* s, int* n);
+const RtBVHNode2*    rth_bvh2_nodes(RthScene* s, int* n);
+const RtBVHNode4*    rth_bvh4_nodes(RthScene* s, int* n);
+const uint32_t*      rth_prim_idx(RthScene* s, int* n);
+const RtTLASNode*    rth_tlas_nodes(RthScene* s, int* n);
+const RtBVHInstance* rth_blas_nodes(RthScene* s, int* n);
+/* BVH statistics (bvh.h:21-22): depth, node count, spatial splits, clipped prims, prim count, SAH cost, build ms. */
+int rth_bvh_stats(RthScene* s, uint32_t out_u[5], float out_f[2]);
+
+/* CameraManager(vfov,type) + origin/forward/aperture/focalLength + UpdateCamVec() (camera.h:24-34,101-121). */
+int rth_camera(int width, int height, float vfov, int type, const float origin[3], const float forward[3],
+               float aperture, float focalLength, RtCamera* out);
+
+/* Renderer mirror (renderer.cpp:6-63): owns a context of librt355.so. */
+RthRenderer* rth_renderer_create(RthScene* scene /* adopted */, int width, int height, int device, int y0, int y1,
+                                 int shading, int sampling, int bvh, int russianRoulette, int filterFireflies);
+void rth_renderer_destroy(RthRenderer* r);
+int  rth_renderer_init(RthRenderer* r);                                   /* Renderer::Init  */
+int  rth_renderer_set_camera(RthRenderer* r, const float origin[3], const float forward[3], float fov, float aperture);
+int  rth_renderer_tick(RthRenderer* r, int frames);                       /* Renderer::Tick x frames */
+int  rth_renderer_read(RthRenderer* r, RtFloat4* out, float* energy);     /* accumBuffer read-back + ComputeEnergy */
+int  rth_renderer_camera(RthRenderer* r, RtCamera* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

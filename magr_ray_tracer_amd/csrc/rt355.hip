@@ -1,0 +1,600 @@
+// rt355.hip — C-ABI implementation (include/rt355.h): device memory, streams, launch
+// sequence.  This is the replacement for the reference's OpenCL Kernel/Buffer dispatch in
+// Renderer (src/renderer.cpp:64-94,142-263,289-301).  No CPU fallback exists here.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/rt355.h"
+#include "rt355_kernels.h"
+
+using namespace rt355dev;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return fail(RT_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+struct RtCtx {
+    RtConfig cfg{};
+    hipStream_t stream = nullptr;
+    DevScene sc{};
+    DevQueues q{};
+    DevVariant var{};
+    int nPix = 0, firstPixel = 0, gridMax = 0;
+    bool sceneLoaded = false, ownAccum = true;
+    std::vector<void*> sceneAllocs, queueAllocs;
+    float* dFocus = nullptr;
+    RtRay* dRayIO = nullptr; // debug import/export staging (lazy)
+    uint64_t frames = 0, primaryRays = 0;
+    // profiling
+    struct Ev { hipEvent_t a, b; int stage; };
+    std::vector<Ev> evPool; size_t evUsed = 0;
+    RtStageTimes times{};
+    int maxDepth2 = 0;
+};
+enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_COMPACT, ST_CONNECT, ST_ACCUM };
+
+extern "C" const char* rt_last_error(void) { return g_err.c_str(); }
+extern "C" int rt_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+template <class T> static int dalloc(std::vector<void*>& bag, T** p, size_t count)
+{
+    void* v = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&v, bytes);
+    if (e != hipSuccess) return fail(RT_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    bag.push_back(v);
+    *p = (T*)v;
+    return RT_OK;
+}
+static void free_bag(std::vector<void*>& bag) { for (void* p : bag) (void)hipFree(p); bag.clear(); }
+
+static size_t stack_bytes(const RtCtx* c) { return (size_t)(c->cfg.accel == RT_ACCEL_BVH4 ? RT_BVH4_STACK : RT_BVH2_STACK) * kBlock * sizeof(uint32_t); }
+
+// ---- profiling brackets --------------------------------------------------------------
+static void ev_begin(RtCtx* c, int stage)
+{
+    if (!c->cfg.profile) return;
+    if (c->evUsed == c->evPool.size()) {
+        RtCtx::Ev e{}; (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); c->evPool.push_back(e);
+    }
+    c->evPool[c->evUsed].stage = stage;
+    (void)hipEventRecord(c->evPool[c->evUsed].a, c->stream);
+}
+static void ev_end(RtCtx* c)
+{
+    if (!c->cfg.profile) return;
+    (void)hipEventRecord(c->evPool[c->evUsed].b, c->stream);
+    c->evUsed++;
+}
+static void ev_collect(RtCtx* c) // call after a stream sync
+{
+    for (size_t i = 0; i < c->evUsed; i++) {
+        float ms = 0; (void)hipEventElapsedTime(&ms, c->evPool[i].a, c->evPool[i].b);
+        switch (c->evPool[i].stage) {
+        case ST_GENERATE: c->times.generate_ms += ms; c->times.generate_launches++; break;
+        case ST_EXTEND:   c->times.extend_ms += ms; c->times.extend_launches++; break;
+        case ST_SHADE:    c->times.shade_ms += ms; c->times.shade_launches++; break;
+        case ST_COMPACT:  c->times.compact_ms += ms; c->times.compact_launches++; break;
+        case ST_CONNECT:  c->times.connect_ms += ms; c->times.connect_launches++; break;
+        case ST_ACCUM:    c->times.accumulate_ms += ms; c->times.accumulate_launches++; break;
+        }
+    }
+    c->evUsed = 0;
+}
+
+// ---- create / destroy ----------------------------------------------------------------
+extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
+{
+    if (!cfg || !out) return fail(RT_E_INVALID, "rt_create: null argument");
+    if (cfg->width <= 0 || cfg->height <= 0) return fail(RT_E_INVALID, "rt_create: bad resolution %dx%d", cfg->width, cfg->height);
+    RtConfig c = *cfg;
+    if (c.y1 <= 0) c.y1 = c.height;
+    if (c.y0 < 0 || c.y0 >= c.y1 || c.y1 > c.height) return fail(RT_E_INVALID, "rt_create: bad row band [%d,%d)", c.y0, c.y1);
+    if (c.max_bounces <= 0) c.max_bounces = RT_MAX_BOUNCES;
+    if (c.max_bounces > RT_MAX_BOUNCES) return fail(RT_E_INVALID, "rt_create: max_bounces %d > %d", c.max_bounces, RT_MAX_BOUNCES);
+    if ((c.shading != RT_SHADING_SIMPLE && c.shading != RT_SHADING_NEE) || (c.sampling != RT_SAMPLING_HEMISPHERE && c.sampling != RT_SAMPLING_COSINE) ||
+        (c.accel != RT_ACCEL_BVH2 && c.accel != RT_ACCEL_BVH4))
+        return fail(RT_E_INVALID, "rt_create: unknown kernel variant");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(RT_E_DEVICE, "rt_create: no HIP device visible (this library has no CPU path)");
+    if (c.device < 0 || c.device >= ndev) return fail(RT_E_INVALID, "rt_create: device %d out of range (%d visible)", c.device, ndev);
+    HIPCHK(hipSetDevice(c.device));
+    RtCtx* ctx = new RtCtx();
+    ctx->cfg = c;
+    ctx->nPix = (c.y1 - c.y0) * c.width;
+    ctx->firstPixel = c.y0 * c.width;
+    ctx->gridMax = (ctx->nPix * std::max(1, c.max_bounces) + kBlock - 1) / kBlock; // connect may cover max_bounces*nPix shadow rays
+    ctx->var = DevVariant{ c.shading, c.sampling, c.accel, c.russian_roulette ? 1 : 0, c.filter_fireflies ? 1 : 0, c.max_bounces };
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return fail(RT_E_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    DevQueues& q = ctx->q;
+    const size_t n = (size_t)ctx->nPix, nS = n * (size_t)c.max_bounces, nW = (n + 63) / 64;
+    int rc = RT_OK;
+    auto& bag = ctx->queueAllocs;
+#define QA(field, count) if (rc == RT_OK) rc = dalloc(bag, &q.field, count)
+    QA(O, n); QA(D, n); QA(inten, n); QA(meta, n); QA(hit, n);
+    QA(tO, n); QA(tD, n); QA(tInten, n); QA(tMeta, n); QA(tsA, n); QA(tsB, n); QA(tsC, n);
+    QA(sA, nS); QA(sB, nS); QA(sC, nS);
+    QA(extMask, nW); QA(shMask, nW); QA(extBase, nW); QA(shBase, nW);
+    QA(nRays, RT_MAX_BOUNCES + 2); QA(nShadow, RT_MAX_BOUNCES + 2);
+    QA(seeds, n); QA(accum, (size_t)c.width * c.height); QA(steps, n);
+    QA(ctrExtend, (size_t)ctx->gridMax * 5); QA(ctrConnect, (size_t)ctx->gridMax * 5);
+#undef QA
+    if (rc == RT_OK) rc = dalloc(bag, &ctx->dFocus, 1);
+    if (rc != RT_OK) { free_bag(bag); (void)hipStreamDestroy(ctx->stream); delete ctx; return rc; }
+    q.nPix = ctx->nPix; q.firstPixel = ctx->firstPixel; q.width = c.width; q.height = c.height;
+    (void)hipMemsetAsync(q.accum, 0, sizeof(float4) * (size_t)c.width * c.height, ctx->stream);
+    (void)hipMemsetAsync(q.nRays, 0, sizeof(int32_t) * (RT_MAX_BOUNCES + 2), ctx->stream);
+    (void)hipMemsetAsync(q.nShadow, 0, sizeof(int32_t) * (RT_MAX_BOUNCES + 2), ctx->stream);
+    (void)hipMemsetAsync(q.ctrExtend, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
+    (void)hipMemsetAsync(q.ctrConnect, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
+    (void)hipMemsetAsync(q.seeds, 0, sizeof(uint32_t) * n, ctx->stream);
+    (void)hipMemsetAsync(q.hit, 0, sizeof(float4) * n, ctx->stream);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *out = ctx;
+    return RT_OK;
+}
+
+extern "C" int rt_destroy(RtCtx* ctx)
+{
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->cfg.device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_bag(ctx->sceneAllocs); free_bag(ctx->queueAllocs);
+    if (ctx->dRayIO) (void)hipFree(ctx->dRayIO);
+    for (auto& e : ctx->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+// ---- scene upload ----------------------------------------------------------------------
+template <class T> static int upload(RtCtx* c, const T** dst, const T* src, size_t count)
+{
+    T* d = nullptr;
+    int rc = dalloc(c->sceneAllocs, &d, count);
+    if (rc != RT_OK) return rc;
+    if (count) HIPCHK(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *dst = d;
+    return RT_OK;
+}
+static int bvh2_depth(const RtBVHNode2* n, int32_t nNodes, uint32_t root)
+{
+    // iterative depth of the subtree at `root`; also validates child indices
+    std::vector<std::pair<uint32_t, int>> st; st.push_back({ root, 0 });
+    int best = 0; size_t visited = 0;
+    while (!st.empty()) {
+        auto [i, d] = st.back(); st.pop_back();
+        if (i >= (uint32_t)nNodes || ++visited > (size_t)nNodes * 2 + 2) return -1;
+        if (d > best) best = d;
+        if (n[i].count == 0) { st.push_back({ n[i].first, d + 1 }); st.push_back({ n[i].first + 1, d + 1 }); }
+    }
+    return best;
+}
+static int bvh4_stack_need(const RtBVHNode4* n, int32_t nNodes, uint32_t root)
+{
+    // worst-case live stack entries of the unordered 4-wide traversal (push every interior child, pop one)
+    std::vector<std::pair<uint32_t, int>> st; st.push_back({ root, 0 });
+    int best = 0; size_t visited = 0;
+    while (!st.empty()) {
+        auto [i, base] = st.back(); st.pop_back();
+        if (i >= (uint32_t)nNodes || ++visited > (size_t)nNodes + 1) return -1;
+        int kids = 0;
+        for (int k = 0; k < 4; k++) if (n[i].first[k] != RT_INVALID && n[i].count[k] == 0) kids++;
+        if (base + kids > best) best = base + kids;
+        int pushed = 0;
+        for (int k = 0; k < 4; k++) if (n[i].first[k] != RT_INVALID && n[i].count[k] == 0) {
+            // child k is popped when the (kids-1-pushed) later siblings are gone: entries below it = base + pushed
+            st.push_back({ (uint32_t)n[i].first[k], base + pushed });
+            pushed++;
+        }
+    }
+    return best;
+}
+
+extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPrims, const RtMaterial* mats, int32_t nMats,
+                               const RtFloat4* textures, int32_t nTexels, const uint32_t* lights, int32_t nLights,
+                               const void* bvhNodes, int32_t nNodes, const uint32_t* primIdx, int32_t nIdx,
+                               const RtTLASNode* tlas, int32_t nTlas, const RtBVHInstance* blas, int32_t nBlas)
+{
+    if (!ctx) return fail(RT_E_INVALID, "rt_upload_scene: null context");
+    if (!prims || nPrims <= 0 || !mats || nMats <= 0 || !bvhNodes || nNodes <= 0 || !primIdx || nIdx <= 0 || !tlas || nTlas <= 0 || !blas || nBlas <= 0)
+        return fail(RT_E_INVALID, "rt_upload_scene: missing array (prims/materials/bvh/primIdx/tlas/blas are required)");
+    if (nLights > 0 && !lights) return fail(RT_E_INVALID, "rt_upload_scene: nLights > 0 but lights == NULL");
+    if (nTexels > 0 && !textures) return fail(RT_E_INVALID, "rt_upload_scene: nTexels > 0 but textures == NULL");
+    // Host-side shape checks: a kernel that walks a malformed tree can fault the GPU.
+    for (int32_t i = 0; i < nPrims; i++) {
+        if (prims[i].matIdx < 0 || prims[i].matIdx >= nMats) return fail(RT_E_INVALID, "primitive %d: matIdx %d out of range", i, prims[i].matIdx);
+        if (prims[i].objType < 0 || prims[i].objType > 2) return fail(RT_E_INVALID, "primitive %d: objType %d", i, prims[i].objType);
+    }
+    for (int32_t i = 0; i < nIdx; i++) if (primIdx[i] >= (uint32_t)nPrims) return fail(RT_E_INVALID, "primIdx[%d] = %u out of range", i, primIdx[i]);
+    for (int32_t i = 0; i < nLights; i++) if (lights[i] >= (uint32_t)nPrims) return fail(RT_E_INVALID, "lights[%d] out of range", i);
+    int64_t texPad = 2; // the reference's lookup can land one row + one texel past a texture (uv == 1): pad the atlas
+    for (int32_t i = 0; i < nMats; i++) if (mats[i].texIdx != -1) {
+        if (mats[i].texIdx < 0 || mats[i].texW <= 0 || mats[i].texH <= 0 ||
+            (int64_t)mats[i].texIdx + (int64_t)mats[i].texW * mats[i].texH > (int64_t)nTexels)
+            return fail(RT_E_INVALID, "material %d: texture window exceeds the atlas", i);
+        texPad = std::max<int64_t>(texPad, (int64_t)mats[i].texW + 2);
+    }
+    for (int32_t i = 0; i < nTlas; i++) {
+        const uint32_t lr = tlas[i].leftRight;
+        if (lr == 0) { if (tlas[i].BLASidx >= (uint32_t)nBlas) return fail(RT_E_INVALID, "tlas node %d: BLASidx out of range", i); }
+        else if ((lr & 0xffffu) >= (uint32_t)nTlas || (lr >> 16) >= (uint32_t)nTlas) return fail(RT_E_INVALID, "tlas node %d: child out of range", i);
+    }
+    const int stackCap = ctx->cfg.accel == RT_ACCEL_BVH4 ? RT_BVH4_STACK : RT_BVH2_STACK;
+    for (int32_t b = 0; b < nBlas; b++) {
+        if (blas[b].bvhIdx >= (uint32_t)nNodes) return fail(RT_E_INVALID, "instance %d: bvhIdx out of range", b);
+        int need = ctx->cfg.accel == RT_ACCEL_BVH4 ? bvh4_stack_need((const RtBVHNode4*)bvhNodes, nNodes, blas[b].bvhIdx)
+                                                   : bvh2_depth((const RtBVHNode2*)bvhNodes, nNodes, blas[b].bvhIdx);
+        if (need < 0) return fail(RT_E_INVALID, "instance %d: malformed BVH (child index out of range or cycle)", b);
+        if (need > stackCap) return fail(RT_E_UNSUPPORTED, "instance %d: traversal needs %d stack entries, the reference kernels provide %d", b, need, stackCap);
+    }
+    if (ctx->cfg.accel == RT_ACCEL_BVH2) {
+        const RtBVHNode2* n2 = (const RtBVHNode2*)bvhNodes;
+        for (int32_t i = 0; i < nNodes; i++) if (n2[i].count > 0 && (uint64_t)n2[i].first + n2[i].count > (uint64_t)nIdx)
+            return fail(RT_E_INVALID, "bvh node %d: leaf range exceeds primIdx", i);
+    } else {
+        const RtBVHNode4* n4 = (const RtBVHNode4*)bvhNodes;
+        for (int32_t i = 0; i < nNodes; i++) for (int k = 0; k < 4; k++) if (n4[i].first[k] != RT_INVALID && n4[i].count[k] > 0 &&
+            (int64_t)n4[i].first[k] + n4[i].count[k] > (int64_t)nIdx) return fail(RT_E_INVALID, "bvh4 node %d: leaf range exceeds primIdx", i);
+    }
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    free_bag(ctx->sceneAllocs);
+    DevScene sc{};
+    int rc = upload(ctx, &sc.prims, prims, (size_t)nPrims);
+    if (rc == RT_OK) rc = upload(ctx, &sc.mats, mats, (size_t)nMats);
+    if (rc == RT_OK) { // zero-padded atlas (see texPad above)
+        float4* t = nullptr;
+        rc = dalloc(ctx->sceneAllocs, &t, (size_t)nTexels + (size_t)texPad);
+        if (rc == RT_OK) {
+            HIPCHK(hipMemset(t, 0, sizeof(float4) * ((size_t)nTexels + (size_t)texPad)));
+            if (nTexels) HIPCHK(hipMemcpy(t, textures, sizeof(float4) * (size_t)nTexels, hipMemcpyHostToDevice));
+            sc.tex = t;
+        }
+    }
+    if (rc == RT_OK) rc = upload(ctx, &sc.lights, lights, (size_t)nLights);
+    if (rc == RT_OK) {
+        if (ctx->cfg.accel == RT_ACCEL_BVH4) rc = upload(ctx, &sc.bvh4, (const RtBVHNode4*)bvhNodes, (size_t)nNodes);
+        else rc = upload(ctx, &sc.bvh2, (const RtBVHNode2*)bvhNodes, (size_t)nNodes);
+    }
+    if (rc == RT_OK) rc = upload(ctx, &sc.primIdx, primIdx, (size_t)nIdx);
+    if (rc == RT_OK) rc = upload(ctx, &sc.tlas, tlas, (size_t)nTlas);
+    if (rc == RT_OK) rc = upload(ctx, &sc.blas, blas, (size_t)nBlas);
+    if (rc != RT_OK) { free_bag(ctx->sceneAllocs); ctx->sceneLoaded = false; return rc; }
+    sc.nLights = nLights; sc.nPrims = nPrims; sc.nBlas = nBlas;
+    ctx->sc = sc;
+    ctx->sceneLoaded = true;
+    return RT_OK;
+}
+
+// ---- seeds / accumulator ---------------------------------------------------------------
+extern "C" int rt_set_seeds(RtCtx* ctx, const uint32_t* seeds, int64_t n)
+{
+    if (!ctx || !seeds) return fail(RT_E_INVALID, "rt_set_seeds: null argument");
+    if (n != ctx->nPix) return fail(RT_E_INVALID, "rt_set_seeds: expected %d seeds (band pixels), got %lld", ctx->nPix, (long long)n);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(ctx->q.seeds, seeds, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+extern "C" int rt_seed_default(RtCtx* ctx)
+{
+    if (!ctx) return fail(RT_E_INVALID, "rt_seed_default: null context");
+    std::vector<uint32_t> s((size_t)ctx->nPix);
+    uint32_t x = 0x12345678u; // template/template.cpp:711
+    auto next = [&x]() { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; };
+    for (int64_t i = 0; i < ctx->firstPixel; i++) next();
+    for (auto& v : s) v = next();
+    return rt_set_seeds(ctx, s.data(), (int64_t)s.size());
+}
+extern "C" int rt_get_seeds(RtCtx* ctx, uint32_t* out, int64_t n)
+{
+    if (!ctx || !out || n != ctx->nPix) return fail(RT_E_INVALID, "rt_get_seeds: bad argument");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out, ctx->q.seeds, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+extern "C" int rt_bind_accum(RtCtx* ctx, void* devicePtr)
+{
+    if (!ctx) return fail(RT_E_INVALID, "rt_bind_accum: null context");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (devicePtr) { ctx->q.accum = (float4*)devicePtr; ctx->ownAccum = false; }
+    else if (!ctx->ownAccum) {
+        float4* a = nullptr;
+        int rc = dalloc(ctx->queueAllocs, &a, (size_t)ctx->cfg.width * ctx->cfg.height);
+        if (rc != RT_OK) return rc;
+        HIPCHK(hipMemset(a, 0, sizeof(float4) * (size_t)ctx->cfg.width * ctx->cfg.height));
+        ctx->q.accum = a; ctx->ownAccum = true;
+    }
+    return RT_OK;
+}
+extern "C" void* rt_accum_device_ptr(RtCtx* ctx) { return ctx ? (void*)ctx->q.accum : nullptr; }
+extern "C" void* rt_stream(RtCtx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int rt_reset(RtCtx* ctx)
+{
+    if (!ctx) return fail(RT_E_INVALID, "rt_reset: null context");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    hipLaunchKernelGGL(k_reset, dim3((ctx->nPix + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream, ctx->q.accum, ctx->firstPixel, ctx->nPix);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+// ---- stages --------------------------------------------------------------------------------
+static int need_scene(RtCtx* ctx, const char* who)
+{
+    if (!ctx) return fail(RT_E_INVALID, "%s: null context", who);
+    if (!ctx->sceneLoaded) return fail(RT_E_INVALID, "%s: no scene uploaded", who);
+    return RT_OK;
+}
+static inline dim3 grid_for(int n) { return dim3((unsigned)std::max(1, (n + kBlock - 1) / kBlock)); }
+
+extern "C" int rt_stage_begin_frame(RtCtx* ctx)
+{
+    if (!ctx) return fail(RT_E_INVALID, "rt_stage_begin_frame: null context");
+    hipLaunchKernelGGL(k_begin_frame, dim3(1), dim3(64), 0, ctx->stream, ctx->q);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+extern "C" int rt_stage_generate(RtCtx* ctx, const RtCamera* cam, const RtSettings* s)
+{
+    if (!ctx || !cam) return fail(RT_E_INVALID, "rt_stage_generate: null argument");
+    ev_begin(ctx, ST_GENERATE);
+    hipLaunchKernelGGL(k_generate, grid_for(ctx->nPix), dim3(kBlock), 0, ctx->stream, ctx->q, *cam, s ? s->antiAliasing : 1);
+    ev_end(ctx);
+    HIPCHK(hipGetLastError());
+    ctx->primaryRays += (uint64_t)ctx->nPix;
+    return RT_OK;
+}
+extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
+{
+    int rc = need_scene(ctx, "rt_stage_extend"); if (rc) return rc;
+    if (bounce < 0 || bounce >= RT_MAX_BOUNCES + 1) return fail(RT_E_INVALID, "rt_stage_extend: bounce %d", bounce);
+    ev_begin(ctx, ST_EXTEND);
+    if (ctx->cfg.accel == RT_ACCEL_BVH4)
+        hipLaunchKernelGGL(k_extend<RT_ACCEL_BVH4>, grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
+    else
+        hipLaunchKernelGGL(k_extend<RT_ACCEL_BVH2>, grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
+    ev_end(ctx);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+extern "C" int rt_stage_shade(RtCtx* ctx, int32_t bounce)
+{
+    int rc = need_scene(ctx, "rt_stage_shade"); if (rc) return rc;
+    if (bounce < 0 || bounce >= RT_MAX_BOUNCES) return fail(RT_E_INVALID, "rt_stage_shade: bounce %d", bounce);
+    ev_begin(ctx, ST_SHADE);
+    if (ctx->cfg.shading == RT_SHADING_NEE)
+        hipLaunchKernelGGL(k_shade<true>, grid_for(ctx->nPix), dim3(kBlock), 0, ctx->stream, ctx->sc, ctx->q, ctx->var, bounce);
+    else
+        hipLaunchKernelGGL(k_shade<false>, grid_for(ctx->nPix), dim3(kBlock), 0, ctx->stream, ctx->sc, ctx->q, ctx->var, bounce);
+    ev_end(ctx);
+    ev_begin(ctx, ST_COMPACT);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->q, bounce);
+    hipLaunchKernelGGL(k_compact, grid_for(ctx->nPix), dim3(kBlock), 0, ctx->stream, ctx->q, bounce);
+    ev_end(ctx);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+extern "C" int rt_stage_connect(RtCtx* ctx, int32_t b0, int32_t b1)
+{
+    int rc = need_scene(ctx, "rt_stage_connect"); if (rc) return rc;
+    if (b0 < 0 || b1 < b0 || b1 >= RT_MAX_BOUNCES) return fail(RT_E_INVALID, "rt_stage_connect: bounce range [%d,%d]", b0, b1);
+    const int cap = ctx->nPix * (b1 - b0 + 1);
+    ev_begin(ctx, ST_CONNECT);
+    if (ctx->cfg.accel == RT_ACCEL_BVH4)
+        hipLaunchKernelGGL(k_connect<RT_ACCEL_BVH4>, grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
+    else
+        hipLaunchKernelGGL(k_connect<RT_ACCEL_BVH2>, grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
+    ev_end(ctx);
+    ev_begin(ctx, ST_ACCUM);
+    for (int b = b0; b <= b1; b++)
+        hipLaunchKernelGGL(k_accumulate, grid_for(ctx->nPix), dim3(kBlock), 0, ctx->stream, ctx->q, b);
+    ev_end(ctx);
+    HIPCHK(hipGetLastError());
+    return RT_OK;
+}
+
+// Renderer::RayTrace() (renderer.cpp:64-94), `frames` times.
+extern "C" int rt_render(RtCtx* ctx, const RtCamera* cam, const RtSettings* settings, int32_t frames)
+{
+    int rc = need_scene(ctx, "rt_render"); if (rc) return rc;
+    if (!cam) return fail(RT_E_INVALID, "rt_render: null camera");
+    if (frames <= 0) return fail(RT_E_INVALID, "rt_render: frames must be > 0");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    const bool nee = ctx->cfg.shading == RT_SHADING_NEE, rr = ctx->cfg.russian_roulette != 0;
+    const int renderBVH = settings ? settings->renderBVH : 0;
+    for (int f = 0; f < frames; f++) {
+        if ((rc = rt_stage_begin_frame(ctx))) return rc;
+        if ((rc = rt_stage_generate(ctx, cam, settings))) return rc;
+        for (int b = 0; b < ctx->cfg.max_bounces; b++) {
+            if ((rc = rt_stage_extend(ctx, b, renderBVH))) return rc;
+            if (renderBVH) break;                                  // renderer.cpp:79
+            if ((rc = rt_stage_shade(ctx, b))) return rc;
+            if (!rr && nee) if ((rc = rt_stage_connect(ctx, b, b))) return rc;   // renderer.cpp:85-87
+        }
+        if (rr && nee && !renderBVH) if ((rc = rt_stage_connect(ctx, 0, ctx->cfg.max_bounces - 1))) return rc; // renderer.cpp:91-92
+        ctx->frames++;
+        if (ctx->cfg.profile && ctx->evUsed > 4096) { HIPCHK(hipStreamSynchronize(ctx->stream)); ev_collect(ctx); }
+    }
+    return RT_OK;
+}
+extern "C" int rt_synchronize(RtCtx* ctx)
+{
+    if (!ctx) return fail(RT_E_INVALID, "rt_synchronize: null context");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ev_collect(ctx);
+    return RT_OK;
+}
+
+extern "C" int rt_focus(RtCtx* ctx, int32_t x, int32_t y, const RtCamera* cam, float* t)
+{
+    int rc = need_scene(ctx, "rt_focus"); if (rc) return rc;
+    if (!cam || !t) return fail(RT_E_INVALID, "rt_focus: null argument");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    if (ctx->cfg.accel == RT_ACCEL_BVH4)
+        hipLaunchKernelGGL(k_focus<RT_ACCEL_BVH4>, dim3(1), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, *cam, x, y, ctx->cfg.width, ctx->cfg.height, ctx->dFocus);
+    else
+        hipLaunchKernelGGL(k_focus<RT_ACCEL_BVH2>, dim3(1), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, *cam, x, y, ctx->cfg.width, ctx->cfg.height, ctx->dFocus);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(t, ctx->dFocus, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_read_accum(RtCtx* ctx, RtFloat4* out)
+{
+    if (!ctx || !out) return fail(RT_E_INVALID, "rt_read_accum: null argument");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ev_collect(ctx);
+    HIPCHK(hipMemcpy(out, ctx->q.accum, sizeof(float4) * (size_t)ctx->cfg.width * ctx->cfg.height, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+static int sum_table(RtCtx* ctx, const unsigned long long* dev, uint64_t out5[5])
+{
+    std::vector<unsigned long long> h((size_t)ctx->gridMax * 5);
+    HIPCHK(hipMemcpy(h.data(), dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 5; k++) out5[k] = 0;
+    for (size_t b = 0; b < (size_t)ctx->gridMax; b++) for (int k = 0; k < 5; k++) out5[k] += h[b * 5 + k];
+    return RT_OK;
+}
+extern "C" int rt_read_counters(RtCtx* ctx, RtCounters* out)
+{
+    if (!ctx || !out) return fail(RT_E_INVALID, "rt_read_counters: null argument");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ev_collect(ctx);
+    uint64_t e[5], c[5];
+    int rc = sum_table(ctx, ctx->q.ctrExtend, e); if (rc) return rc;
+    rc = sum_table(ctx, ctx->q.ctrConnect, c); if (rc) return rc;
+    memset(out, 0, sizeof *out);
+    out->extend_rays = e[0]; out->extend_tlas_visits = e[1]; out->extend_inst_visits = e[2]; out->extend_node_visits = e[3]; out->extend_prim_tests = e[4];
+    out->connect_rays = c[0]; out->connect_tlas_visits = c[1]; out->connect_inst_visits = c[2]; out->connect_node_visits = c[3]; out->connect_prim_tests = c[4];
+    out->primary_rays = ctx->primaryRays; out->shadow_rays = c[0]; out->frames = ctx->frames;
+    return RT_OK;
+}
+extern "C" int rt_reset_counters(RtCtx* ctx)
+{
+    if (!ctx) return fail(RT_E_INVALID, "rt_reset_counters: null context");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemset(ctx->q.ctrExtend, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5));
+    HIPCHK(hipMemset(ctx->q.ctrConnect, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5));
+    ctx->frames = 0; ctx->primaryRays = 0;
+    return RT_OK;
+}
+extern "C" int rt_read_stage_times(RtCtx* ctx, RtStageTimes* out)
+{
+    if (!ctx || !out) return fail(RT_E_INVALID, "rt_read_stage_times: null argument");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ev_collect(ctx);
+    *out = ctx->times;
+    return RT_OK;
+}
+extern "C" int rt_reset_stage_times(RtCtx* ctx)
+{
+    if (!ctx) return fail(RT_E_INVALID, "rt_reset_stage_times: null context");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ev_collect(ctx);
+    memset(&ctx->times, 0, sizeof ctx->times);
+    return RT_OK;
+}
+
+// ---- debug import/export ----------------------------------------------------------------------
+static int ray_io(RtCtx* ctx)
+{
+    if (!ctx->dRayIO) HIPCHK(hipMalloc((void**)&ctx->dRayIO, sizeof(RtRay) * (size_t)ctx->nPix));
+    return RT_OK;
+}
+static int read_count(RtCtx* ctx, const int32_t* dev, int32_t* out)
+{
+    HIPCHK(hipMemcpyAsync(out, dev, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+extern "C" int rt_debug_get_rays(RtCtx* ctx, int32_t bounce, RtRay* out, int32_t capacity, int32_t* n)
+{
+    int rc = need_scene(ctx, "rt_debug_get_rays"); if (rc) return rc;
+    if (!n || bounce < 0 || bounce > RT_MAX_BOUNCES) return fail(RT_E_INVALID, "rt_debug_get_rays: bad argument");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    if ((rc = read_count(ctx, ctx->q.nRays + bounce, n))) return rc;
+    if (!out) return RT_OK;
+    if (*n > capacity) return fail(RT_E_INVALID, "rt_debug_get_rays: capacity %d < %d rays", capacity, *n);
+    if ((rc = ray_io(ctx))) return rc;
+    if (*n > 0) {
+        hipLaunchKernelGGL(k_export_rays, grid_for(*n), dim3(kBlock), 0, ctx->stream, ctx->sc, ctx->q, bounce, ctx->dRayIO);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out, ctx->dRayIO, sizeof(RtRay) * (size_t)*n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return RT_OK;
+}
+extern "C" int rt_debug_set_rays(RtCtx* ctx, int32_t bounce, const RtRay* in, int32_t n)
+{
+    if (!ctx || !in || n < 0 || n > ctx->nPix || bounce < 0 || bounce > RT_MAX_BOUNCES) return fail(RT_E_INVALID, "rt_debug_set_rays: bad argument");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    int rc = ray_io(ctx); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (n > 0) {
+        HIPCHK(hipMemcpy(ctx->dRayIO, in, sizeof(RtRay) * (size_t)n, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_import_rays, grid_for(n), dim3(kBlock), 0, ctx->stream, ctx->q, ctx->dRayIO, n);
+    }
+    hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, ctx->stream, ctx->q.nRays + bounce, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+extern "C" int rt_debug_get_shadow(RtCtx* ctx, int32_t b0, int32_t b1, RtShadowRecord* out, int32_t capacity, int32_t* n)
+{
+    if (!ctx || !n || b0 < 0 || b1 < b0 || b1 >= RT_MAX_BOUNCES) return fail(RT_E_INVALID, "rt_debug_get_shadow: bad argument");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    int32_t lo = 0, hi = 0, rc;
+    if ((rc = read_count(ctx, ctx->q.nShadow + b0, &lo))) return rc;
+    if ((rc = read_count(ctx, ctx->q.nShadow + b1 + 1, &hi))) return rc;
+    *n = hi - lo;
+    if (!out) return RT_OK;
+    if (*n > capacity) return fail(RT_E_INVALID, "rt_debug_get_shadow: capacity %d < %d", capacity, *n);
+    std::vector<float4> a((size_t)*n), b((size_t)*n), c((size_t)*n);
+    if (*n > 0) {
+        HIPCHK(hipMemcpy(a.data(), ctx->q.sA + lo, sizeof(float4) * a.size(), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(b.data(), ctx->q.sB + lo, sizeof(float4) * b.size(), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(c.data(), ctx->q.sC + lo, sizeof(float4) * c.size(), hipMemcpyDeviceToHost));
+    }
+    for (int32_t i = 0; i < *n; i++) {
+        RtShadowRecord r;
+        r.ox = a[i].x; r.oy = a[i].y; r.oz = a[i].z; r.tmax = a[i].w;
+        r.lx = b[i].x; r.ly = b[i].y; r.lz = b[i].z; memcpy(&r.pixelIdx, &b[i].w, 4);
+        r.radiance = RtFloat4{ c[i].x, c[i].y, c[i].z, c[i].w };
+        out[i] = r;
+    }
+    return RT_OK;
+}
+extern "C" int rt_debug_get_steps(RtCtx* ctx, int32_t* out, int32_t capacity, int32_t* n)
+{
+    if (!ctx || !n) return fail(RT_E_INVALID, "rt_debug_get_steps: bad argument");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *n = ctx->nPix;
+    if (!out) return RT_OK;
+    if (capacity < ctx->nPix) return fail(RT_E_INVALID, "rt_debug_get_steps: capacity too small");
+    HIPCHK(hipMemcpy(out, ctx->q.steps, sizeof(int32_t) * (size_t)ctx->nPix, hipMemcpyDeviceToHost));
+    return RT_OK;
+}

@@ -1,0 +1,776 @@
+// rt355_kernels.h — hand-written HIP kernels (gfx950 / CDNA4, wave64) for the wavefront
+// path tracer hot path: generate -> extend -> shade -> (compact) -> connect.
+//
+// What each kernel replaces in the reference (paths relative to the reference repo):
+//   k_generate  src/cl/wavefront.cl:14-34  + camera.cl:6-46, ray.cl:4-19
+//   k_extend    src/cl/wavefront.cl:35-75  + tlas.cl:3-77, bvh.cl:3-96, primitives.cl:11-89
+//   k_shade     src/cl/wavefront.cl:76-142 + shading.cl:7-169, ray.cl:21-72, glass.cl:4-49,
+//               primitives.cl:91-189, skydome.cl:5-7
+//   k_connect   src/cl/wavefront.cl:144-201
+//   k_focus     src/cl/wavefront.cl:203-224, k_reset :226-229
+//
+// Design (DESIGN.md has the full rationale):
+//  * Ray queues are struct-of-arrays of 16-byte elements (O, D, intensity, {t,prim,u,v},
+//    8-byte meta) so a wave reads 1 KiB contiguous per instruction, instead of the
+//    reference's 128-byte AoS Ray updated in place in global memory.
+//  * Schedule S1 of SURVEY.md §8(c): queue slot g is shaded with RNG stream seeds[g] and
+//    survivors keep their relative order.  The reference's global atomic_inc/atomic_dec
+//    counters become per-wave __ballot masks + popcount prefix (k_shade), one ordered
+//    scan over the wave counts (k_scan) and a scatter (k_compact): deterministic.
+//  * The traversal stack lives in LDS (one column per lane, conflict-free); the ray
+//    lives in registers; results are written once.
+//  * Float discipline = oracle/oracle.c header: IEEE + - * /, sqrt; dot/cross as the fma
+//    chains of ROCm's OpenCL library; compiled with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/rt355_types.h"
+
+namespace rt355dev {
+
+#define RT_FORCEINLINE __device__ __forceinline__
+static constexpr int   kBlock = 256;           // threads per workgroup = 4 wave64
+static constexpr float kEps = RT_EPSILON;
+static constexpr float kFar = RT_REALLYFAR;
+static constexpr float kPi = 3.14159274101257f;     // M_PI_F
+static constexpr float kInvPi = 0.31830987334251f;  // M_1_PI_F
+
+// ------------------------------------------------------------------ device views
+struct DevScene {
+    const RtPrimitive*   prims;
+    const RtMaterial*    mats;
+    const float4*        tex;
+    const uint32_t*      lights;
+    const RtBVHNode2*    bvh2;
+    const RtBVHNode4*    bvh4;
+    const uint32_t*      primIdx;
+    const RtTLASNode*    tlas;
+    const RtBVHInstance* blas;
+    int32_t nLights, nPrims, nBlas;
+};
+struct DevQueues {
+    // live queue (compacted), capacity nPix
+    float4* O; float4* D; float4* inten; uint2* meta; float4* hit;
+    // per-slot staging written by shade (uncompacted)
+    float4* tO; float4* tD; float4* tInten; uint2* tMeta;
+    float4* tsA; float4* tsB; float4* tsC;
+    // shadow queue (compacted), capacity max_bounces * nPix
+    float4* sA; float4* sB; float4* sC;
+    unsigned long long* extMask; unsigned long long* shMask;
+    uint32_t* extBase; uint32_t* shBase;
+    int32_t* nRays;    // [RT_MAX_BOUNCES+2]  rays entering bounce b
+    int32_t* nShadow;  // [RT_MAX_BOUNCES+2]  shadow rays of bounce b occupy [nShadow[b], nShadow[b+1])
+    uint32_t* seeds;   // one RNG stream per band slot
+    float4* accum;     // full frame, indexed by global pixel index
+    int32_t* steps;    // per-ray steps of the last extend (debug / heat map), may be null
+    unsigned long long* ctrExtend;  // [gridMax][5] per-block partial work counters
+    unsigned long long* ctrConnect; // [gridMax][5]
+    int32_t nPix, firstPixel, width, height;
+};
+struct DevVariant { int32_t shading, sampling, accel, rr, fireflies, maxBounces; };
+
+// meta.y bit layout
+static constexpr uint32_t kMetaBounceMask = 0xffu, kMetaInside = 0x100u, kMetaLastSpec = 0x200u;
+
+// ------------------------------------------------------------------ float4 helpers
+RT_FORCEINLINE float4 mk4(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
+RT_FORCEINLINE float4 splat(float s) { return make_float4(s, s, s, s); }
+RT_FORCEINLINE float4 add4(float4 a, float4 b) { return mk4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+RT_FORCEINLINE float4 sub4(float4 a, float4 b) { return mk4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+RT_FORCEINLINE float4 mul4(float4 a, float4 b) { return mk4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+RT_FORCEINLINE float4 muls(float4 a, float s) { return mk4(a.x * s, a.y * s, a.z * s, a.w * s); }
+RT_FORCEINLINE float4 neg4(float4 a) { return mk4(-a.x, -a.y, -a.z, -a.w); }
+RT_FORCEINLINE float4 ld4(const RtFloat4& v) { return *reinterpret_cast<const float4*>(&v); }
+RT_FORCEINLINE float dot3(float4 a, float4 b) { return __fmaf_rn(a.z, b.z, __fmaf_rn(a.y, b.y, a.x * b.x)); }
+RT_FORCEINLINE float dot4(float4 a, float4 b) { return __fmaf_rn(a.w, b.w, __fmaf_rn(a.z, b.z, __fmaf_rn(a.y, b.y, a.x * b.x))); }
+RT_FORCEINLINE float4 cross4(float4 a, float4 b)
+{
+    return mk4(__fmaf_rn(a.y, b.z, b.y * (-a.z)), __fmaf_rn(a.z, b.x, b.z * (-a.x)), __fmaf_rn(a.x, b.y, b.x * (-a.y)), 0.0f);
+}
+RT_FORCEINLINE float length4(float4 v)
+{
+    float d = dot4(v, v);
+    if (d < 1.17549435e-38f) { float4 s = muls(v, 0x1p+86f); return sqrtf(dot4(s, s)) * 0x1p-86f; }
+    if (d == INFINITY) { float4 s = muls(v, 0x1p-66f); return sqrtf(dot4(s, s)) * 0x1p+66f; }
+    return sqrtf(d);
+}
+RT_FORCEINLINE float sel_inf(float x) { return copysignf(isinf(x) ? 1.0f : 0.0f, x); }
+RT_FORCEINLINE float4 normalize4(float4 v)
+{
+    if (v.x == 0.0f && v.y == 0.0f && v.z == 0.0f && v.w == 0.0f) return v;
+    float d = dot4(v, v);
+    if (d < 1.17549435e-38f) { v = muls(v, 0x1p+86f); d = dot4(v, v); }
+    else if (d == INFINITY) {
+        v = muls(v, 0x1p-66f); d = dot4(v, v);
+        if (d == INFINITY) { v = mk4(sel_inf(v.x), sel_inf(v.y), sel_inf(v.z), sel_inf(v.w)); d = dot4(v, v); }
+    }
+    float r = 1.0f / sqrtf(d);
+    return muls(v, r);
+}
+
+// ------------------------------------------------------------------ RNG (util.cl:50-59)
+RT_FORCEINLINE uint32_t rng_next(uint32_t& s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
+RT_FORCEINLINE float rnd_float(uint32_t& s) { return (float)rng_next(s) * 2.3283064365387e-10f; }
+RT_FORCEINLINE float rnd_abs(uint32_t& s) { return fabsf(rnd_float(s)); }
+RT_FORCEINLINE float4 rnd_float3(uint32_t& s) { float x = rnd_float(s), y = rnd_float(s), z = rnd_float(s); return mk4(x, y, z, 0.0f); }
+
+// ------------------------------------------------------------------ traversal ray (registers)
+// Inside an instance the reference's transformRay() zeroes the w lanes (tlas.cl:5-7), and
+// AABB tests only read xyz, so traversal carries xyz only and w == 0 in primitive tests.
+struct TRay {
+    float ox, oy, oz, dx, dy, dz, rx, ry, rz;
+    float t; int prim; float u, v;
+};
+struct WorkCtr { uint32_t tlas, inst, node, prim; };
+
+RT_FORCEINLINE float slab(const TRay& r, float4 bmin, float4 bmax) // bvh.cl:3-12
+{
+    float tx1 = (bmin.x - r.ox) * r.rx, tx2 = (bmax.x - r.ox) * r.rx;
+    float tmin = fminf(tx1, tx2), tmax = fmaxf(tx1, tx2);
+    float ty1 = (bmin.y - r.oy) * r.ry, ty2 = (bmax.y - r.oy) * r.ry;
+    tmin = fmaxf(tmin, fminf(ty1, ty2)); tmax = fminf(tmax, fmaxf(ty1, ty2));
+    float tz1 = (bmin.z - r.oz) * r.rz, tz2 = (bmax.z - r.oz) * r.rz;
+    tmin = fmaxf(tmin, fminf(tz1, tz2)); tmax = fminf(tmax, fmaxf(tz1, tz2));
+    return (tmax >= tmin && tmin < r.t && tmax > 0) ? tmin : kFar;
+}
+
+RT_FORCEINLINE void test_prim(const DevScene& sc, int idx, TRay& r) // primitives.cl:11-89
+{
+    const RtPrimitive* p = sc.prims + idx;
+    const int type = p->objType;
+    const float4 O = mk4(r.ox, r.oy, r.oz, 0.0f), D = mk4(r.dx, r.dy, r.dz, 0.0f);
+    if (type == RT_PRIM_TRIANGLE) {
+        const float4 v0 = ld4(p->obj.triangle.v0), v1 = ld4(p->obj.triangle.v1), v2 = ld4(p->obj.triangle.v2);
+        float4 v0v1 = sub4(v1, v0), v0v2 = sub4(v2, v0);
+        float4 pvec = cross4(D, v0v2);
+        float det = dot4(v0v1, pvec);
+        if (fabsf(det) < 1e-8f) return;
+        float invDet = 1.0f / det;
+        float4 tvec = sub4(O, v0);
+        float u = dot4(tvec, pvec) * invDet;
+        if (u < 0 || u > 1) return;
+        float4 qvec = cross4(tvec, v0v1);
+        float v = dot4(D, qvec) * invDet;
+        if (v < 0 || u + v > 1) return;
+        float t = dot4(v0v2, qvec) * invDet;
+        if (t > r.t || t < 0) return;
+        r.t = t; r.prim = idx; r.u = u; r.v = v;
+    } else if (type == RT_PRIM_SPHERE) {
+        const float4 pos = ld4(p->obj.sphere.pos);
+        const float r2 = p->obj.sphere.r2;
+        float4 oc = sub4(O, pos);
+        float b = dot4(oc, D);
+        float c = dot4(oc, oc) - r2;
+        float d = b * b - c;
+        if (d <= 0) return;
+        d = sqrtf(d);
+        float t = -b - d;
+        if (t < r.t && t > 0) { r.t = t; r.prim = idx; return; }
+        t = d - b;
+        if (t < r.t && t > 0) { r.t = t; r.prim = idx; return; }
+    } else if (type == RT_PRIM_PLANE) {
+        const float4 N = ld4(p->obj.plane.N);
+        float t = -(dot4(O, N) + p->obj.plane.d) / dot4(D, N);
+        if (t > r.t || t < 0) return;
+        r.t = t; r.prim = idx;
+        float4 uAxis = mk4(N.y, N.z, -N.x, 0.0f);
+        float4 vAxis = cross4(uAxis, N);
+        float4 I = add4(O, muls(D, r.t));
+        r.u = dot4(I, uAxis); r.v = dot4(I, vAxis);
+    }
+}
+
+// Stack column of this lane in LDS: entry e lives at stk[e * kBlock + tid].
+#define STK(e) stk[(e) * kBlock + threadIdx.x]
+
+// BVH2 traversal, bvh.cl:13-54.  Returns `steps` (or -1 when OCC and a hit closer than
+// t_light exists).  `root` is the instance's bvhIdx; child ids are absolute.
+template <bool OCC>
+RT_FORCEINLINE int traverse_bvh2(const DevScene& sc, TRay& r, uint32_t root, uint32_t* stk, WorkCtr& wc)
+{
+    const RtBVHNode2* nodes = sc.bvh2;
+    uint32_t node = root, sp = 0;
+    int steps = 0;
+    const float tLight = r.t;
+    for (;;) {
+        const uint2 fc = *reinterpret_cast<const uint2*>(&nodes[node].first);
+        if (fc.y > 0) {
+            for (uint32_t i = 0; i < fc.y; i++) {
+                int index = (int)sc.primIdx[fc.x + i];
+                wc.prim++;
+                test_prim(sc, index, r);
+                if (OCC && r.t < tLight) return -1;
+            }
+            if (sp == 0) break;
+            node = STK(--sp);
+            continue;
+        }
+        wc.node++;
+        uint32_t c1 = fc.x, c2 = fc.x + 1;
+        float d1 = slab(r, ld4(nodes[c1].aabbMin), ld4(nodes[c1].aabbMax));
+        float d2 = slab(r, ld4(nodes[c2].aabbMin), ld4(nodes[c2].aabbMax));
+        if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t c = c1; c1 = c2; c2 = c; }
+        if (d1 >= tLight) {
+            if (sp == 0) break;
+            node = STK(--sp);
+        } else {
+            steps++;
+            node = c1;
+            if (d2 < tLight) { STK(sp) = c2; sp++; steps++; }
+        }
+    }
+    return steps;
+}
+
+// BVH4 traversal, bvh.cl:55-96 (children visited in slot order, all four distances taken
+// at node entry).
+template <bool OCC>
+RT_FORCEINLINE int traverse_bvh4(const DevScene& sc, TRay& r, uint32_t root, uint32_t* stk, WorkCtr& wc)
+{
+    const RtBVHNode4* nodes = sc.bvh4;
+    uint32_t node = root, sp = 0;
+    int steps = 0;
+    const float tLight = r.t;
+    for (;;) {
+        steps++; wc.node++;
+        const RtBVHNode4* n = nodes + node;
+        const int4 first = *reinterpret_cast<const int4*>(n->first);
+        const int4 count = *reinterpret_cast<const int4*>(n->count);
+        const int f[4] = { first.x, first.y, first.z, first.w };
+        const int c[4] = { count.x, count.y, count.z, count.w };
+        float dist[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            dist[k] = f[k] != RT_INVALID ? slab(r, ld4(n->aabbMin[k]), ld4(n->aabbMax[k])) : kFar;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (f[k] == RT_INVALID) continue;
+            if (dist[k] >= tLight) continue;
+            if (c[k] > 0) {
+                for (uint32_t j = 0; j < (uint32_t)c[k]; j++) {
+                    int index = (int)sc.primIdx[f[k] + j];
+                    wc.prim++;
+                    test_prim(sc, index, r);
+                    if (OCC && r.t < tLight) return -1;
+                }
+            } else {
+                STK(sp) = (uint32_t)f[k]; sp++;
+            }
+        }
+        if (sp == 0) break;
+        node = STK(--sp);
+    }
+    return steps;
+}
+
+// instanceIntersect, tlas.cl:9-26 with transformRay :3-8 and util.cl:61-87.
+template <int ACCEL, bool OCC>
+RT_FORCEINLINE int traverse_instance(const DevScene& sc, TRay& r, const RtBVHInstance* inst, uint32_t* stk, WorkCtr& wc)
+{
+    const float* T = inst->invT;
+    const float bx = r.ox, by = r.oy, bz = r.oz, bdx = r.dx, bdy = r.dy, bdz = r.dz, brx = r.rx, bry = r.ry, brz = r.rz;
+    const float4 Dv = mk4(bdx, bdy, bdz, 0.0f), Ov = mk4(bx, by, bz, 0.0f);
+    r.dx = dot3(mk4(T[0], T[1], T[2], 0), Dv); r.dy = dot3(mk4(T[4], T[5], T[6], 0), Dv); r.dz = dot3(mk4(T[8], T[9], T[10], 0), Dv);
+    r.ox = dot3(mk4(T[0], T[1], T[2], 0), Ov) + T[3]; r.oy = dot3(mk4(T[4], T[5], T[6], 0), Ov) + T[7];
+    r.oz = dot3(mk4(T[8], T[9], T[10], 0), Ov) + T[11];
+    r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
+    wc.inst++;
+    int steps = ACCEL == RT_ACCEL_BVH4 ? traverse_bvh4<OCC>(sc, r, inst->bvhIdx, stk, wc)
+                                       : traverse_bvh2<OCC>(sc, r, inst->bvhIdx, stk, wc);
+    r.ox = bx; r.oy = by; r.oz = bz; r.dx = bdx; r.dy = bdy; r.dz = bdz; r.rx = brx; r.ry = bry; r.rz = brz;
+    return steps;
+}
+
+// intersectTLAS, tlas.cl:28-77.  The TLAS stack (<= 32 entries of 16-bit ids) is a
+// private array; with a single BLAS the root is a leaf and it is never touched.
+template <int ACCEL, bool OCC>
+RT_FORCEINLINE int traverse_tlas(const DevScene& sc, TRay& r, uint32_t* stk, WorkCtr& wc)
+{
+    const RtTLASNode* tl = sc.tlas;
+    uint16_t tstack[RT_TLAS_STACK];
+    uint32_t node = 0, sp = 0;
+    int steps = 0;
+    const float tLight = r.t;
+    for (;;) {
+        const uint2 lr = *reinterpret_cast<const uint2*>(&tl[node].leftRight);
+        if (lr.x == 0) {
+            int value = traverse_instance<ACCEL, OCC>(sc, r, sc.blas + lr.y, stk, wc);
+            if (OCC && value == -1) return -1;
+            steps += value;
+            if (sp == 0) break;
+            node = tstack[--sp];
+            continue;
+        }
+        wc.tlas++;
+        uint32_t c1 = lr.x & 0xffffu, c2 = lr.x >> 16;
+        float d1 = slab(r, ld4(tl[c1].aabbMin), ld4(tl[c1].aabbMax));
+        float d2 = slab(r, ld4(tl[c2].aabbMin), ld4(tl[c2].aabbMax));
+        if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t c = c1; c1 = c2; c2 = c; }
+        if (d1 >= tLight) {
+            if (sp == 0) break;
+            node = tstack[--sp];
+        } else {
+            node = c1;
+            if (d2 < tLight) tstack[sp++] = (uint16_t)c2;
+        }
+    }
+    return steps;
+}
+
+// Sum a lane's work counters over the workgroup and add them to this block's row of the
+// per-block partial table (no atomics: one row per blockIdx, launches are stream-ordered).
+RT_FORCEINLINE void flush_counters(unsigned long long* table, uint32_t rays, const WorkCtr& wc, uint32_t* red /* >= 5*4 words LDS */)
+{
+    uint32_t v[5] = { rays, wc.tlas, wc.inst, wc.node, wc.prim };
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads(); // LDS stack columns are dead past this point
+    if (lane == 0) for (int k = 0; k < 5; k++) red[wave * 5 + k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        unsigned long long s = 0;
+        for (int w = 0; w < kBlock / 64; w++) s += red[w * 5 + threadIdx.x];
+        table[(size_t)blockIdx.x * 5 + threadIdx.x] += s;
+    }
+}
+
+// ------------------------------------------------------------------ k_reset / k_begin
+__global__ void k_reset(float4* accum, int32_t first, int32_t n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) accum[first + i] = splat(0.0f);
+}
+__global__ void k_begin_frame(DevQueues q) // renderer.cpp:66-69
+{
+    if (threadIdx.x == 0) { q.nRays[0] = q.nPix; q.nShadow[0] = 0; }
+}
+
+// ------------------------------------------------------------------ k_generate
+RT_FORCEINLINE void primary_ray(const RtCamera& cam, int x, int y, int W, int H, int aa, uint32_t& seed, float4& O, float4& D)
+{
+    if (cam.type == RT_CAM_PROJECTION) { // camera.cl:9-24
+        float u = (float)x * (1.0f / (float)W);
+        float v = (float)y * (1.0f / (float)H);
+        if (aa) { u += rnd_float(seed) / (float)W; v += rnd_float(seed) / (float)H; }
+        float4 P = add4(add4(ld4(cam.topLeft), muls(ld4(cam.horizontal), u)), muls(ld4(cam.vertical), v));
+        float4 dir = normalize4(sub4(P, ld4(cam.origin)));
+        float4 focalPoint = add4(ld4(cam.origin), muls(dir, cam.focalLength));
+        O = add4(ld4(cam.origin), muls(sub4(rnd_float3(seed), splat(0.5f)), cam.aperture));
+        D = normalize4(sub4(focalPoint, O));
+    } else { // camera.cl:25-44
+        float u = ((float)x - (float)W * .5f) * (2.f / (float)W);
+        float v = ((float)y - (float)H * .5f) * (2.f / (float)H);
+        if (aa) { u += rnd_float(seed) / (float)W; v += rnd_float(seed) / (float)H; }
+        float r2 = u * u + v * v;
+        if (r2 > 1.0f) { O = splat(0.0f); D = splat(0.0f); return; }
+        float rr = sqrtf(r2);
+        float psi = rr * cam.fov * kPi / 180.0f;
+        float sinPsi = sinf(psi), cosPsi = cosf(psi);
+        float sinAlpha = u / rr, cosAlpha = v / rr;
+        D = sub4(add4(muls(ld4(cam.up), sinPsi * cosAlpha), muls(ld4(cam.right), sinPsi * sinAlpha)), muls(ld4(cam.forward), cosPsi));
+        O = ld4(cam.origin);
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_generate(DevQueues q, RtCamera cam, int aa)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= q.nPix) return;
+    const int idx = q.firstPixel + i;
+    uint32_t seed = q.seeds[i];
+    float4 O, D;
+    primary_ray(cam, idx % q.width, idx / q.width, q.width, q.height, aa, seed, O, D);
+    q.seeds[i] = seed;
+    q.O[i] = O; q.D[i] = D; q.inten[i] = splat(1.0f);
+    q.meta[i] = make_uint2((uint32_t)idx, kMetaLastSpec); // bounces 0, inside 0, lastSpecular 1
+}
+
+// ------------------------------------------------------------------ k_extend (variant 0: one ray per lane)
+template <int ACCEL>
+__global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int bounce, int renderBVH)
+{
+    extern __shared__ uint32_t stk[];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int n = q.nRays[bounce];
+    WorkCtr wc = { 0, 0, 0, 0 };
+    uint32_t rays = 0;
+    if (i < n) {
+        const float4 O = q.O[i], D = q.D[i];
+        TRay r;
+        r.ox = O.x; r.oy = O.y; r.oz = O.z; r.dx = D.x; r.dy = D.y; r.dz = D.z;
+        r.rx = 1.0f / D.x; r.ry = 1.0f / D.y; r.rz = 1.0f / D.z;
+        r.t = kFar; r.prim = -1; r.u = 0.0f; r.v = 0.0f;
+        int steps = traverse_tlas<ACCEL, false>(sc, r, stk, wc);
+        rays = 1;
+        q.hit[i] = mk4(r.t, __int_as_float(r.prim), r.u, r.v);
+        if (q.steps) q.steps[i] = steps;
+        if (renderBVH) q.accum[q.firstPixel + i] = splat((float)(uint32_t)steps / 255.f); // wavefront.cl:67
+    }
+    flush_counters(q.ctrExtend, rays, wc, stk);
+}
+
+// ------------------------------------------------------------------ shading helpers
+struct SRay { // the reference Ray fields shade() reads and writes
+    float4 O, D, N, I, inten;
+    float t, u, v; int prim, bounces, pixel; bool inside, lastSpec;
+};
+struct ExtRay { float4 O, D, inten; int bounces; bool inside, lastSpec, valid; };
+
+RT_FORCEINLINE float4 prim_normal(const RtPrimitive* p, float4 I) // primitives.cl:91-105
+{
+    const int type = p->objType;
+    if (type == RT_PRIM_SPHERE) return muls(sub4(I, ld4(p->obj.sphere.pos)), p->obj.sphere.invr);
+    if (type == RT_PRIM_PLANE) return ld4(p->obj.plane.N);
+    return ld4(p->obj.triangle.N);
+}
+RT_FORCEINLINE float4 albedo_of(const DevScene& sc, const RtPrimitive* prim, const RtMaterial* mat, const SRay& ray) // primitives.cl:107-148
+{
+    float4 albedo = ld4(mat->color);
+    const int texIdx = mat->texIdx;
+    if (texIdx != -1) {
+        const int texW = mat->texW, texH = mat->texH, type = prim->objType;
+        if (type == RT_PRIM_TRIANGLE) {
+            const RtTriangle* t = &prim->obj.triangle;
+            float w2 = 1 - ray.u - ray.v;
+            float ux = fmodf(ray.u * t->uv1.x + ray.v * t->uv0.x + w2 * t->uv2.x, 1.f);
+            float uy = fmodf(ray.u * t->uv1.y + ray.v * t->uv0.y + w2 * t->uv2.y, 1.f);
+            if (ux < 0) ux = 1 + ux;
+            if (uy < 0) uy = 1 + uy;
+            int x = (int)(ux * (float)texW), y = (int)(uy * (float)texH);
+            albedo = sc.tex[texIdx + x + y * texW];
+        } else if (type == RT_PRIM_SPHERE) {
+            float ux = (float)((1 + atan2f(ray.N.z, ray.N.x) / 3.14159265358979323846) * 0.5);
+            float uy = acosf(ray.N.y) / 3.14159265358979323846f;
+            int x = (int)(ux * (float)texW), y = (int)(uy * (float)texH);
+            albedo = sc.tex[texIdx + x + y * texW];
+        } else {
+            float u = fmodf(ray.u, 1.f), v = fmodf(ray.v, 1.f);
+            if (u < 0) u = 1 - u;
+            if (v < 0) v = 1 - v;
+            int x = (int)(u * (float)texW), y = (int)(v * (float)texH);
+            albedo = sc.tex[texIdx + (x + y * texW)];
+        }
+    }
+    return albedo;
+}
+RT_FORCEINLINE float survival_prob(float4 a) { return fminf(fmaxf(fmaxf(a.x, fmaxf(a.y, a.z)), 0.f), 1.f); } // primitives.cl:150-153
+RT_FORCEINLINE float4 random_point_on(const RtPrimitive* p, uint32_t& seed) // primitives.cl:155-189
+{
+    if (p->objType == RT_PRIM_SPHERE) {
+        float theta = rnd_abs(seed) * 2.0f * kPi;
+        float u = rnd_abs(seed) * 2.0f - 1.0f;
+        float pre = sqrtf(1 - u * u);
+        float x = cosf(theta) * pre, y = sinf(theta) * pre;
+        return add4(muls(mk4(x, y, u, 0.0f), p->obj.sphere.r), ld4(p->obj.sphere.pos));
+    }
+    const float4 v0 = ld4(p->obj.triangle.v0), v1 = ld4(p->obj.triangle.v1), v2 = ld4(p->obj.triangle.v2);
+    float u1 = rnd_abs(seed), u2 = rnd_abs(seed);
+    if (u1 + u2 > 1) { u1 = 1 - u1; u2 = 1 - u2; }
+    float4 a = sub4(v1, v0), b = sub4(v2, v0);
+    return add4(add4(v0, muls(a, u1)), muls(b, u2));
+}
+RT_FORCEINLINE float4 sample_ball(uint32_t& seed) // ray.cl:49-53,62-69 (w lane = -1 before normalising)
+{
+    float4 p = sub4(muls(rnd_float3(seed), 2.0f), splat(1.0f));
+    while (p.x * p.x + p.y * p.y + p.z * p.z > 1.0f) p = sub4(muls(rnd_float3(seed), 2.0f), splat(1.0f));
+    return normalize4(p);
+}
+RT_FORCEINLINE float4 sample_dir(int sampling, float4 N, uint32_t& seed) // ray.cl:46-72
+{
+    float4 p = sample_ball(seed);
+    if (sampling == RT_SAMPLING_HEMISPHERE) return dot4(N, p) < 0.0f ? neg4(p) : p;
+    return normalize4(add4(N, p));
+}
+RT_FORCEINLINE ExtRay reflect_ray(const SRay& ray) // ray.cl:21-29 (inside resets to false)
+{
+    float dnd = dot4(ray.N, ray.D);
+    float4 reflected = sub4(ray.D, muls(muls(ray.N, 2.0f), dnd));
+    ExtRay e;
+    e.O = add4(ray.I, muls(muls(reflected, 2.0f), kEps));
+    e.D = reflected; e.inten = ray.inten; e.bounces = ray.bounces + 1; e.inside = false; e.lastSpec = false; e.valid = true;
+    return e;
+}
+RT_FORCEINLINE ExtRay transmit_ray(const SRay& ray, float4 T) // ray.cl:31-39
+{
+    ExtRay e;
+    e.O = add4(ray.I, muls(T, kEps));
+    e.D = T; e.inten = ray.inten; e.bounces = ray.bounces + 1; e.inside = !ray.inside; e.lastSpec = false; e.valid = true;
+    return e;
+}
+RT_FORCEINLINE float fresnel(SRay& ray, const RtMaterial* mat, float4& outT) // glass.cl:4-49
+{
+    float costhetai = dot4(ray.N, muls(ray.D, -1.0f));
+    float n1 = mat->n1, n2 = mat->n2;
+    if (ray.inside) {
+        n1 = mat->n2; n2 = mat->n1;
+        ray.inten.x *= expf(-mat->absorption.x * ray.t);
+        ray.inten.y *= expf(-mat->absorption.y * ray.t);
+        ray.inten.z *= expf(-mat->absorption.z * ray.t);
+    }
+    float frac = n1 * (1 / n2);
+    float k = 1 - frac * frac * (1 - costhetai * costhetai);
+    if (k < 0) return 1.f;
+    outT = normalize4(add4(muls(ray.D, frac), muls(ray.N, frac * costhetai - sqrtf(k))));
+    float costhetat = dot4(neg4(ray.N), outT);
+    float n1ci = n1 * costhetai, n2ci = n2 * costhetai, n1ct = n1 * costhetat, n2ct = n2 * costhetat;
+    float frac1 = (n1ci - n2ct) / (n1ci + n2ct);
+    float frac2 = (n1ct - n2ci) / (n1ct + n2ci);
+    float Fr = 0.5f * (frac1 * frac1 + frac2 * frac2);
+    return mat->specular + (1 - mat->specular) * Fr;
+}
+RT_FORCEINLINE float4 firefly(int on, float4 c) // wavefront.cl:125-127,196-198
+{
+    if (on && dot4(c, c) > 25) return muls(normalize4(c), 5.0f);
+    return c;
+}
+
+struct ShadowOut { float4 a, b, c; bool valid; };
+
+// neeShading (shading.cl:72-169) and kajiyaShading (:7-70) in one body; NEE selects the
+// light-sampling block and the lastSpecular rules.
+template <bool NEE>
+RT_FORCEINLINE float4 shade_hit(const DevScene& sc, const DevVariant& var, SRay& ray, uint32_t& seed, ExtRay& ext, ShadowOut& sh)
+{
+    const RtPrimitive* prim = sc.prims + ray.prim;
+    const RtMaterial* mat = sc.mats + prim->matIdx;
+    if (mat->isLight) {
+        if (NEE && !ray.lastSpec) return splat(0.0f);
+        return mul4(ray.inten, ld4(mat->emittance));
+    }
+    const float rnd = rnd_float(seed);
+    if (mat->isDielectric) {
+        float4 T = splat(0.0f);
+        float Fr = fresnel(ray, mat, T);
+        ext = rnd < Fr ? reflect_ray(ray) : transmit_ray(ray, T);
+        if (NEE) ext.lastSpec = true;
+    } else if (rnd < mat->specular) {
+        ext = reflect_ray(ray);
+        if (NEE) ext.lastSpec = true;
+    } else {
+        const float4 albedo = albedo_of(sc, prim, mat, ray);
+        const float4 BRDF = muls(albedo, kInvPi);
+        if (NEE && sc.nLights > 0) {
+            uint32_t li = (uint32_t)floorf(rnd_abs(seed) * (float)sc.nLights);
+            if (li >= (uint32_t)sc.nLights) li = (uint32_t)sc.nLights - 1; // reference reads out of bounds here (draw == 1.0)
+            const uint32_t lightIdx = sc.lights[li];
+            const RtPrimitive* lp = sc.prims + lightIdx;
+            float4 pl = random_point_on(lp, seed);
+            float4 dirToLight = sub4(pl, ray.I);
+            float4 Nl = prim_normal(lp, pl);
+            float dist = length4(dirToLight);
+            float4 L = muls(dirToLight, 1 / dist);
+            float dotNL = dot4(ray.N, L);
+            if (dotNL > 0 && dot4(Nl, neg4(L)) > 0) {
+                // The shadow ray carries what connect() needs (wavefront.cl:175-199): its
+                // origin/direction/t_max and the radiance it adds when unoccluded.
+                float4 sInt = muls(ray.inten, (float)sc.nLights);
+                float solidAngle = dot4(Nl, neg4(L)) * lp->area * (1 / (dist * dist));
+                float4 lightColor = ld4(sc.mats[lp->matIdx].emittance);
+                float4 Ld = muls(mul4(muls(lightColor, solidAngle), BRDF), dotNL);
+                float4 color = firefly(var.fireflies, mul4(Ld, sInt));
+                float4 so = add4(ray.I, muls(L, kEps));
+                sh.a = mk4(so.x, so.y, so.z, dist - 2 * kEps);
+                sh.b = mk4(L.x, L.y, L.z, __int_as_float(ray.pixel));
+                sh.c = color;
+                sh.valid = true;
+            }
+        }
+        if (var.rr) {
+            float rr_p = survival_prob(albedo);
+            if (rr_p < rnd_float(seed)) return splat(0.0f);
+            ray.inten = muls(ray.inten, 1 / rr_p);
+        }
+        float4 refl = sample_dir(var.sampling, ray.N, seed);
+        float dotNR = dot4(ray.N, refl);
+        float I_PDF = var.sampling == RT_SAMPLING_HEMISPHERE ? 2 * kPi : dotNR * kPi;
+        ext.O = add4(ray.I, muls(refl, kEps));
+        ext.D = refl;
+        if (NEE) ext.inten = muls(muls(mul4(ray.inten, BRDF), I_PDF), dotNR);         // shading.cl:161
+        else     ext.inten = mul4(ray.inten, muls(muls(BRDF, I_PDF), dotNR));         // shading.cl:60
+        ext.bounces = ray.bounces + 1; ext.inside = ray.inside; ext.lastSpec = false; ext.valid = true;
+    }
+    return splat(0.0f);
+}
+
+// ------------------------------------------------------------------ k_shade
+template <bool NEE>
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevQueues q, DevVariant var, int bounce)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int n = q.nRays[bounce];
+    ExtRay ext; ext.valid = false;
+    ShadowOut sh; sh.valid = false;
+    if (i < n) {
+        const float4 hit = q.hit[i];
+        const uint2 meta = q.meta[i];
+        SRay ray;
+        ray.O = q.O[i]; ray.D = q.D[i]; ray.inten = q.inten[i];
+        ray.t = hit.x; ray.prim = __float_as_int(hit.y); ray.u = hit.z; ray.v = hit.w;
+        ray.pixel = (int)meta.x; ray.bounces = (int)(meta.y & kMetaBounceMask);
+        ray.inside = (meta.y & kMetaInside) != 0; ray.lastSpec = (meta.y & kMetaLastSpec) != 0;
+        if (ray.prim == -1) { // wavefront.cl:109-112, sky = skydome.cl:7
+            float4 c = mul4(ray.inten, mk4(0.0784f, 0.0941f, 0.3215f, 0.0f));
+            q.accum[ray.pixel] = add4(q.accum[ray.pixel], c);
+        } else {
+            // what extend() leaves in the ray (wavefront.cl:69-72)
+            ray.I = add4(ray.O, muls(ray.D, ray.t));
+            ray.N = prim_normal(sc.prims + ray.prim, ray.I);
+            if (dot4(ray.N, neg4(ray.D)) < 0) ray.N = muls(ray.N, -1.0f);
+            uint32_t seed = q.seeds[i];
+            float4 color = shade_hit<NEE>(sc, var, ray, seed, ext, sh);
+            q.seeds[i] = seed;
+            color = firefly(var.fireflies, color);
+            // one path per pixel and launch: the add is race-free; adding an exact zero is skipped
+            if (color.x != 0.0f || color.y != 0.0f || color.z != 0.0f || color.w != 0.0f)
+                q.accum[ray.pixel] = add4(q.accum[ray.pixel], color);
+            if (ext.valid && ext.bounces <= RT_MAX_BOUNCES) { // wavefront.cl:129
+                q.tO[i] = ext.O; q.tD[i] = ext.D; q.tInten[i] = ext.inten;
+                q.tMeta[i] = make_uint2((uint32_t)ray.pixel, (uint32_t)ext.bounces | (ext.inside ? kMetaInside : 0u) | (ext.lastSpec ? kMetaLastSpec : 0u));
+            } else ext.valid = false;
+            if (sh.valid) { q.tsA[i] = sh.a; q.tsB[i] = sh.b; q.tsC[i] = sh.c; }
+        }
+    }
+    // wave-level compaction votes (replaces atomic_inc on numOutRays / shadowRays)
+    const unsigned long long em = __ballot(ext.valid), sm = __ballot(sh.valid);
+    if ((threadIdx.x & 63) == 0) {
+        const int w = i >> 6;
+        if (w * 64 < n) { q.extMask[w] = em; q.shMask[w] = sm; }
+    }
+}
+
+// ------------------------------------------------------------------ k_scan: ordered prefix over the wave votes
+__global__ __launch_bounds__(1024) void k_scan(DevQueues q, int bounce)
+{
+    __shared__ uint32_t sE[1024], sS[1024];
+    const int n = q.nRays[bounce];
+    const int nW = (n + 63) >> 6;
+    const int per = (nW + 1023) / 1024;
+    const int w0 = threadIdx.x * per, w1 = min(w0 + per, nW);
+    uint32_t e = 0, s = 0;
+    for (int w = w0; w < w1; w++) { e += __popcll(q.extMask[w]); s += __popcll(q.shMask[w]); }
+    sE[threadIdx.x] = e; sS[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
+        uint32_t ae = threadIdx.x >= off ? sE[threadIdx.x - off] : 0, as = threadIdx.x >= off ? sS[threadIdx.x - off] : 0;
+        __syncthreads();
+        sE[threadIdx.x] += ae; sS[threadIdx.x] += as;
+        __syncthreads();
+    }
+    uint32_t be = sE[threadIdx.x] - e, bs = sS[threadIdx.x] - s;
+    for (int w = w0; w < w1; w++) {
+        q.extBase[w] = be; q.shBase[w] = bs;
+        be += __popcll(q.extMask[w]); bs += __popcll(q.shMask[w]);
+    }
+    if (threadIdx.x == 1023) { q.nRays[bounce + 1] = (int)sE[1023]; q.nShadow[bounce + 1] = q.nShadow[bounce] + (int)sS[1023]; }
+}
+
+// ------------------------------------------------------------------ k_compact: stable scatter of survivors
+__global__ __launch_bounds__(kBlock) void k_compact(DevQueues q, int bounce)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int n = q.nRays[bounce];
+    if (i >= n) return;
+    const int w = i >> 6, lane = i & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long em = q.extMask[w], sm = q.shMask[w];
+    if ((em >> lane) & 1ull) {
+        const uint32_t dst = q.extBase[w] + __popcll(em & below);
+        q.O[dst] = q.tO[i]; q.D[dst] = q.tD[i]; q.inten[dst] = q.tInten[i]; q.meta[dst] = q.tMeta[i];
+    }
+    if ((sm >> lane) & 1ull) {
+        const uint32_t dst = (uint32_t)q.nShadow[bounce] + q.shBase[w] + __popcll(sm & below);
+        q.sA[dst] = q.tsA[i]; q.sB[dst] = q.tsB[i]; q.sC[dst] = q.tsC[i];
+    }
+}
+
+// ------------------------------------------------------------------ k_connect: any-hit over shadow rays [nShadow[b0], nShadow[b1+1])
+template <int ACCEL>
+__global__ __launch_bounds__(kBlock) void k_connect(DevScene sc, DevQueues q, int b0, int b1)
+{
+    extern __shared__ uint32_t stk[];
+    const int first = q.nShadow[b0], n = q.nShadow[b1 + 1] - first;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    WorkCtr wc = { 0, 0, 0, 0 };
+    uint32_t rays = 0;
+    if (i < n) {
+        const float4 a = q.sA[first + i], b = q.sB[first + i];
+        TRay r;
+        r.ox = a.x; r.oy = a.y; r.oz = a.z; r.dx = b.x; r.dy = b.y; r.dz = b.z;
+        r.rx = 1.0f / b.x; r.ry = 1.0f / b.y; r.rz = 1.0f / b.z;
+        r.t = a.w; r.prim = -1; r.u = 0.0f; r.v = 0.0f;
+        rays = 1;
+        if (traverse_tlas<ACCEL, true>(sc, r, stk, wc) == -1) q.sC[first + i] = splat(0.0f); // occluded: contributes nothing
+    }
+    flush_counters(q.ctrConnect, rays, wc, stk);
+}
+
+// Ordered accumulation of one bounce's shadow contributions: within a bounce every pixel owns
+// at most one shadow ray, so the plain add is race-free; bounces are launched in order, which
+// reproduces the accumulation order of schedule S1 bit for bit.
+__global__ __launch_bounds__(kBlock) void k_accumulate(DevQueues q, int bounce)
+{
+    const int first = q.nShadow[bounce], n = q.nShadow[bounce + 1] - first;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = q.sC[first + i];
+    if (c.x == 0.0f && c.y == 0.0f && c.z == 0.0f && c.w == 0.0f) return;
+    const int pix = __float_as_int(q.sB[first + i].w);
+    q.accum[pix] = add4(q.accum[pix], c);
+}
+
+// ------------------------------------------------------------------ k_focus (wavefront.cl:203-224)
+template <int ACCEL>
+__global__ void k_focus(DevScene sc, RtCamera cam, int x, int y, int W, int H, float* out)
+{
+    extern __shared__ uint32_t stk[];
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float u = (float)x * (1.0f / (float)W), v = (float)y * (1.0f / (float)H); // camera.cl:48-55
+    float4 P = add4(add4(ld4(cam.topLeft), muls(ld4(cam.horizontal), u)), muls(ld4(cam.vertical), v));
+    float4 D = normalize4(sub4(P, ld4(cam.origin)));
+    float4 O = ld4(cam.origin);
+    TRay r;
+    r.ox = O.x; r.oy = O.y; r.oz = O.z; r.dx = D.x; r.dy = D.y; r.dz = D.z;
+    r.rx = 1.0f / D.x; r.ry = 1.0f / D.y; r.rz = 1.0f / D.z;
+    r.t = kFar; r.prim = -1; r.u = r.v = 0.0f;
+    WorkCtr wc = { 0, 0, 0, 0 };
+    traverse_tlas<ACCEL, false>(sc, r, stk, wc);
+    *out = r.t;
+}
+
+// ------------------------------------------------------------------ debug import/export (parity tests)
+__global__ void k_export_rays(DevScene sc, DevQueues q, int bounce, RtRay* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q.nRays[bounce]) return;
+    RtRay r;
+    const float4 O = q.O[i], D = q.D[i], hit = q.hit[i], inten = q.inten[i];
+    const uint2 meta = q.meta[i];
+    float4 rD = mk4(1.0f / D.x, 1.0f / D.y, 1.0f / D.z, 1.0f / D.w);
+    float4 I = splat(0.0f), N = splat(0.0f);
+    const int prim = __float_as_int(hit.y);
+    if (prim != -1) {
+        I = add4(O, muls(D, hit.x));
+        N = prim_normal(sc.prims + prim, I);
+        if (dot4(N, neg4(D)) < 0) N = muls(N, -1.0f);
+    }
+    *reinterpret_cast<float4*>(&r.O) = O; *reinterpret_cast<float4*>(&r.D) = D; *reinterpret_cast<float4*>(&r.rD) = rD;
+    *reinterpret_cast<float4*>(&r.N) = N; *reinterpret_cast<float4*>(&r.I) = I; *reinterpret_cast<float4*>(&r.intensity) = inten;
+    r.t = hit.x; r.primIdx = prim; r.bounces = (int)(meta.y & kMetaBounceMask); r.pixelIdx = (int)meta.x;
+    r.inside = (meta.y & kMetaInside) ? 1 : 0; r.lastSpecular = (meta.y & kMetaLastSpec) ? 1 : 0;
+    r._pad0[0] = r._pad0[1] = 0; r.u = hit.z; r.v = hit.w; r._pad1 = 0;
+    out[i] = r;
+}
+__global__ void k_import_rays(DevQueues q, const RtRay* in, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RtRay r = in[i];
+    q.O[i] = ld4(r.O); q.D[i] = ld4(r.D); q.inten[i] = ld4(r.intensity);
+    q.hit[i] = mk4(r.t, __int_as_float(r.primIdx), r.u, r.v);
+    q.meta[i] = make_uint2((uint32_t)r.pixelIdx, (uint32_t)r.bounces | (r.inside ? kMetaInside : 0u) | (r.lastSpecular ? kMetaLastSpec : 0u));
+}
+__global__ void k_set_count(int32_t* p, int32_t v) { *p = v; }
+
+} // namespace rt355dev

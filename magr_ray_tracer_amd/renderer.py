@@ -1,0 +1,212 @@
+"""Device: Python face of one librt355.so context (one per GPU), i.e. the launch/upload half
+of the reference's Renderer (src/renderer.cpp:64-94,142-263,289-301) behind the C-ABI of
+include/rt355.h.  Everything that computes runs in the HIP kernels; this file only moves
+pointers.  `Renderer` wraps the C++ Renderer mirror (Init / Tick / FocusCamera / energy).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class Device:
+    def __init__(self, width, height, y0=0, y1=None, shading=_lib.SHADING_NEE, sampling=_lib.SAMPLING_COSINE,
+                 accel=_lib.ACCEL_BVH2, russian_roulette=True, filter_fireflies=True, max_bounces=_lib.MAX_BOUNCES,
+                 device=0, profile=False, extend_variant=0):
+        self._lib = _lib.device_lib()
+        cfg = np.zeros((), dtype=_lib.Config)
+        cfg["width"], cfg["height"], cfg["y0"], cfg["y1"] = width, height, y0, height if y1 is None else y1
+        cfg["max_bounces"], cfg["shading"], cfg["sampling"], cfg["accel"] = max_bounces, shading, sampling, accel
+        cfg["russian_roulette"], cfg["filter_fireflies"] = int(russian_roulette), int(filter_fireflies)
+        cfg["device"], cfg["profile"], cfg["extend_variant"] = device, int(profile), extend_variant
+        self.cfg = cfg
+        self.width, self.height = width, height
+        self.y0, self.y1 = int(cfg["y0"]), int(cfg["y1"])
+        self.npix = (self.y1 - self.y0) * width
+        self.first_pixel = self.y0 * width
+        self.accel = accel
+        h = C.c_void_p()
+        self._h = None
+        self._chk(self._lib.rt_create(cfg.ctypes.data_as(C.c_void_p), C.byref(h)))
+        self._h = h
+        self._keep = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RtError(self._lib.rt_last_error().decode())
+
+    def close(self):
+        if self._h:
+            self._lib.rt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- uploads (renderer.cpp:160-208)
+    def upload(self, sa):
+        nodes = sa.nodes(self.accel)
+        P = _lib.ptr
+        self._chk(self._lib.rt_upload_scene(
+            self._h, P(sa.prims), len(sa.prims), P(sa.mats), len(sa.mats), P(sa.tex) if len(sa.tex) else None, len(sa.tex),
+            P(sa.lights) if len(sa.lights) else None, len(sa.lights), P(nodes), len(nodes), P(sa.primIdx), len(sa.primIdx),
+            P(sa.tlas), len(sa.tlas), P(sa.blas), len(sa.blas)))
+
+    def set_seeds(self, seeds):
+        s = np.ascontiguousarray(seeds, dtype=np.uint32)
+        self._chk(self._lib.rt_set_seeds(self._h, _lib.ptr(s), s.size))
+
+    def seed_default(self):
+        self._chk(self._lib.rt_seed_default(self._h))
+
+    def get_seeds(self):
+        s = np.zeros(self.npix, dtype=np.uint32)
+        self._chk(self._lib.rt_get_seeds(self._h, _lib.ptr(s), s.size))
+        return s
+
+    def bind_accum(self, tensor):
+        """Render into a torch CUDA tensor of shape (H, W, 4) float32 (kept alive by this object)."""
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.numel() == self.width * self.height * 4
+        self._keep = tensor
+        self._chk(self._lib.rt_bind_accum(self._h, C.c_void_p(tensor.data_ptr())))
+
+    # ---- frame (renderer.cpp:26-94)
+    def reset(self):
+        self._chk(self._lib.rt_reset(self._h))
+
+    def render(self, cam, frames=1, antiAliasing=1, renderBVH=0):
+        s = np.zeros((), dtype=_lib.Settings)
+        s["antiAliasing"], s["renderBVH"] = antiAliasing, renderBVH
+        c = np.ascontiguousarray(cam)
+        self._chk(self._lib.rt_render(self._h, c.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), int(frames)))
+
+    def synchronize(self):
+        self._chk(self._lib.rt_synchronize(self._h))
+
+    def focus(self, x, y, cam):
+        t = C.c_float(0)
+        c = np.ascontiguousarray(cam)
+        self._chk(self._lib.rt_focus(self._h, int(x), int(y), c.ctypes.data_as(C.c_void_p), C.byref(t)))
+        return np.float32(t.value)
+
+    def read_accum(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        self._chk(self._lib.rt_read_accum(self._h, _lib.ptr(out)))
+        return out
+
+    def counters(self):
+        c = np.zeros((), dtype=_lib.Counters)
+        self._chk(self._lib.rt_read_counters(self._h, c.ctypes.data_as(C.c_void_p)))
+        return {k: int(c[k]) for k in c.dtype.names}
+
+    def reset_counters(self):
+        self._chk(self._lib.rt_reset_counters(self._h))
+
+    def stage_times(self):
+        t = np.zeros((), dtype=_lib.StageTimes)
+        self._chk(self._lib.rt_read_stage_times(self._h, t.ctypes.data_as(C.c_void_p)))
+        return {k: (float(t[k]) if k.endswith("_ms") else int(t[k])) for k in t.dtype.names}
+
+    def reset_stage_times(self):
+        self._chk(self._lib.rt_reset_stage_times(self._h))
+
+    # ---- single stages (parity tests)
+    def stage_begin_frame(self):
+        self._chk(self._lib.rt_stage_begin_frame(self._h))
+
+    def stage_generate(self, cam, antiAliasing=1):
+        s = np.zeros((), dtype=_lib.Settings)
+        s["antiAliasing"] = antiAliasing
+        c = np.ascontiguousarray(cam)
+        self._chk(self._lib.rt_stage_generate(self._h, c.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p)))
+
+    def stage_extend(self, bounce, renderBVH=0):
+        self._chk(self._lib.rt_stage_extend(self._h, bounce, renderBVH))
+
+    def stage_shade(self, bounce):
+        self._chk(self._lib.rt_stage_shade(self._h, bounce))
+
+    def stage_connect(self, b0, b1):
+        self._chk(self._lib.rt_stage_connect(self._h, b0, b1))
+
+    def get_rays(self, bounce):
+        n = C.c_int32(0)
+        self._chk(self._lib.rt_debug_get_rays(self._h, bounce, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=_lib.Ray)
+        if n.value:
+            self._chk(self._lib.rt_debug_get_rays(self._h, bounce, _lib.ptr(out), n.value, C.byref(n)))
+        return out
+
+    def set_rays(self, bounce, rays):
+        r = np.ascontiguousarray(rays, dtype=_lib.Ray)
+        self._chk(self._lib.rt_debug_set_rays(self._h, bounce, _lib.ptr(r) if len(r) else _lib.ptr(np.zeros(1, dtype=_lib.Ray)), len(r)))
+
+    def get_shadow(self, b0, b1):
+        n = C.c_int32(0)
+        self._chk(self._lib.rt_debug_get_shadow(self._h, b0, b1, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=_lib.ShadowRecord)
+        if n.value:
+            self._chk(self._lib.rt_debug_get_shadow(self._h, b0, b1, _lib.ptr(out), n.value, C.byref(n)))
+        return out
+
+    def get_steps(self):
+        n = C.c_int32(0)
+        out = np.zeros(self.npix, dtype=np.int32)
+        self._chk(self._lib.rt_debug_get_steps(self._h, _lib.ptr(out), out.size, C.byref(n)))
+        return out
+
+
+class Renderer:
+    """The C++ Renderer mirror (host/renderer.cpp): Init(), Tick(), accumulator read-back, energy."""
+
+    def __init__(self, scene, width, height, device=0, y0=0, y1=-1, shading=_lib.SHADING_NEE, sampling=_lib.SAMPLING_COSINE,
+                 bvh=_lib.ACCEL_BVH2, russian_roulette=True, filter_fireflies=True):
+        self._lib = _lib.host_lib()
+        self.width, self.height = width, height
+        self._h = self._lib.rth_renderer_create(scene._h, width, height, device, y0, y1, shading, sampling, bvh,
+                                                int(russian_roulette), int(filter_fireflies))
+        if not self._h:
+            raise RtError(self._lib.rth_last_error().decode())
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise RtError(self._lib.rth_last_error().decode())
+
+    def SetCamera(self, origin, forward, fov=110.0, aperture=0.1):
+        self._chk(self._lib.rth_renderer_set_camera(self._h, _lib.fvec(origin), _lib.fvec(forward), float(fov), float(aperture)))
+
+    def Init(self):
+        self._chk(self._lib.rth_renderer_init(self._h))
+
+    def Tick(self, frames=1):
+        self._chk(self._lib.rth_renderer_tick(self._h, int(frames)))
+
+    def camera(self):
+        cam = np.zeros((), dtype=_lib.Camera)
+        self._chk(self._lib.rth_renderer_camera(self._h, cam.ctypes.data_as(C.c_void_p)))
+        return cam
+
+    def read(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        e = C.c_float(0)
+        self._chk(self._lib.rth_renderer_read(self._h, _lib.ptr(out), C.byref(e)))
+        return out, float(e.value)
+
+    def close(self):
+        if self._h:
+            self._lib.rth_renderer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,697 @@
+/* oracle.c — TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * Plain-C restatement of the reference's wavefront hot path.  Every function names
+ * the reference lines it follows (paths relative to the reference repository).
+ *
+ * Float discipline (what "the reference result" means here): the arithmetic of the
+ * reference's OpenCL C source as the ROCm 7.2 OpenCL compiler builds it for gfx950
+ * WITHOUT fast-math (-O2 -ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt,
+ * see oracle/build_ref.sh): source-level + - * / are separate IEEE binary32
+ * operations; the builtins dot() and cross() are the fused-multiply-add chains of
+ * ROCm's OpenCL library (dot: x*x' then fma y, z, w; cross: fma(a.y,b.z,-(a.z*b.y)));
+ * length() and normalize() carry that library's rescaling branches; min/max are
+ * minNum/maxNum.  ONE deliberate difference: the library's normalize() multiplies by
+ * the hardware reciprocal square root (v_rsq_f32, 1 ulp, not reproducible off the
+ * GPU); here and in the HIP path it is v * (1.0f / sqrtf(d)) with IEEE sqrt and
+ * divide, so directions can differ from the reference build in the last 1-2 ulp.
+ * Transcendentals (sin, cos, exp, acospi, atan2pi: fisheye camera, sphere lights,
+ * sphere textures, dielectrics) come from libm here and are not bit-pinned.
+ *
+ * Build: gcc -O2 -ffp-contract=off -mfma -fopenmp (oracle/Makefile).
+ */
+#include "oracle.h"
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef RtFloat4 f4;
+
+/* ---------------------------------------------------------------- vector helpers */
+static inline f4 v4(float x, float y, float z, float w) { f4 r = { x, y, z, w }; return r; }
+static inline f4 splat(float s) { return v4(s, s, s, s); }
+static inline f4 add4(f4 a, f4 b) { return v4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+static inline f4 sub4(f4 a, f4 b) { return v4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+static inline f4 mul4(f4 a, f4 b) { return v4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+static inline f4 muls(f4 a, float s) { return v4(a.x * s, a.y * s, a.z * s, a.w * s); }
+static inline f4 neg4(f4 a) { return v4(-a.x, -a.y, -a.z, -a.w); }
+/* ROCm OpenCL library dot(float3/float4): x*x' then fma in y, z, (w) order. */
+static inline float dot3(f4 a, f4 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline float dot4(f4 a, f4 b) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))); }
+/* ROCm OpenCL library cross(float4): w = 0. */
+static inline f4 cross4(f4 a, f4 b)
+{
+    return v4(fmaf(a.y, b.z, b.y * (-a.z)), fmaf(a.z, b.x, b.z * (-a.x)), fmaf(a.x, b.y, b.x * (-a.y)), 0.0f);
+}
+static inline float length4(f4 v)
+{
+    float d = dot4(v, v);
+    if (d < FLT_MIN) { f4 s = muls(v, 0x1p+86f); return sqrtf(dot4(s, s)) * 0x1p-86f; }
+    if (d == INFINITY) { f4 s = muls(v, 0x1p-66f); return sqrtf(dot4(s, s)) * 0x1p+66f; }
+    return sqrtf(d);
+}
+static inline f4 normalize4(f4 v)
+{
+    if (v.x == 0.0f && v.y == 0.0f && v.z == 0.0f && v.w == 0.0f) return v;
+    float d = dot4(v, v);
+    if (d < FLT_MIN) { v = muls(v, 0x1p+86f); d = dot4(v, v); }
+    else if (d == INFINITY) {
+        v = muls(v, 0x1p-66f); d = dot4(v, v);
+        if (d == INFINITY) {
+            v = v4(copysignf(isinf(v.x) ? 1.0f : 0.0f, v.x), copysignf(isinf(v.y) ? 1.0f : 0.0f, v.y),
+                   copysignf(isinf(v.z) ? 1.0f : 0.0f, v.z), copysignf(isinf(v.w) ? 1.0f : 0.0f, v.w));
+            d = dot4(v, v);
+        }
+    }
+    float r = 1.0f / sqrtf(d); /* reference build: v_rsq_f32 (file header) */
+    return muls(v, r);
+}
+
+/* ---------------------------------------------------------------- RNG (util.cl:50-59) */
+uint32_t orc_xorshift32(uint32_t* s)
+{
+    uint32_t x = *s;
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    *s = x;
+    return x;
+}
+static inline float rnd_float(uint32_t* s) { return (float)orc_xorshift32(s) * 2.3283064365387e-10f; } /* util.cl:57 */
+static inline float rnd_abs(uint32_t* s) { return fabsf(rnd_float(s)); }                                 /* util.cl:58 */
+static inline f4 rnd_float3(uint32_t* s) { float x = rnd_float(s), y = rnd_float(s), z = rnd_float(s); return v4(x, y, z, 0.0f); } /* util.cl:59 */
+
+/* Host seed stream: seeds[i] = (first+i+1)-th xorshift32 output from 0x12345678
+ * (renderer.cpp:195-196, template/template.cpp:711,724-730). */
+void orc_seed_stream(uint32_t* seeds, int64_t first, int64_t n)
+{
+    uint32_t s = 0x12345678u;
+    for (int64_t i = 0; i < first; i++) orc_xorshift32(&s);
+    for (int64_t i = 0; i < n; i++) seeds[i] = orc_xorshift32(&s);
+}
+
+/* ---------------------------------------------------------------- rays (ray.cl) */
+static inline void init_ray(RtRay* r, f4 O, f4 D) /* ray.cl:4-19; pixelIdx,u,v stay as they are */
+{
+    r->O = O; r->D = D;
+    r->rD = v4(1.0f / D.x, 1.0f / D.y, 1.0f / D.z, 1.0f / D.w);
+    r->N = splat(0.0f); r->I = splat(0.0f); r->intensity = splat(1.0f);
+    r->t = 1e30f; r->primIdx = -1; r->bounces = 0; r->inside = 0; r->lastSpecular = 0;
+}
+static inline RtRay zero_ray(void) { RtRay r; memset(&r, 0, sizeof r); return r; }
+
+static RtRay reflect_ray(const RtRay* ray) /* ray.cl:21-29 */
+{
+    float dnd = dot4(ray->N, ray->D);
+    f4 reflected = sub4(ray->D, muls(muls(ray->N, 2.0f), dnd));   /* D - (2*N)*dot */
+    f4 origin = add4(ray->I, muls(muls(reflected, 2.0f), RT_EPSILON)); /* I + (reflected*2)*EPSILON */
+    RtRay r = zero_ray(); init_ray(&r, origin, reflected);
+    r.intensity = ray->intensity; r.bounces = ray->bounces + 1;
+    return r;
+}
+static RtRay transmit_ray(const RtRay* ray, f4 T) /* ray.cl:31-39 */
+{
+    f4 origin = add4(ray->I, muls(T, RT_EPSILON));
+    RtRay r = zero_ray(); init_ray(&r, origin, T);
+    r.intensity = ray->intensity; r.bounces = ray->bounces + 1; r.inside = !ray->inside;
+    return r;
+}
+static f4 sample_ball(uint32_t* seed) /* ray.cl:49-53 / 62-69: reject outside the unit ball (xyz); w = -1 */
+{
+    f4 p = sub4(muls(rnd_float3(seed), 2.0f), splat(1.0f));
+    while (p.x * p.x + p.y * p.y + p.z * p.z > 1.0f) p = sub4(muls(rnd_float3(seed), 2.0f), splat(1.0f));
+    return normalize4(p);
+}
+static f4 random_ray_hemisphere(f4 N, uint32_t* seed) /* ray.cl:46-56 */
+{
+    f4 p = sample_ball(seed);
+    return dot4(N, p) < 0.0f ? neg4(p) : p;
+}
+static f4 cosine_ray_hemisphere(f4 N, uint32_t* seed) /* ray.cl:59-72 */
+{
+    f4 p = sample_ball(seed);
+    return normalize4(add4(N, p));
+}
+
+/* ---------------------------------------------------------------- camera (camera.cl) */
+static void primary_ray(RtRay* r, int x, int y, const RtCamera* cam, int aa, int W, int H, uint32_t* seed) /* camera.cl:6-46 */
+{
+    if (cam->type == RT_CAM_PROJECTION) {
+        float u = (float)x * (1.0f / (float)W);
+        float v = (float)y * (1.0f / (float)H);
+        if (aa) { u += rnd_float(seed) / (float)W; v += rnd_float(seed) / (float)H; }
+        f4 P = add4(add4(cam->topLeft, muls(cam->horizontal, u)), muls(cam->vertical, v));
+        f4 dir = normalize4(sub4(P, cam->origin));
+        f4 focalPoint = add4(cam->origin, muls(dir, cam->focalLength));
+        f4 O = add4(cam->origin, muls(sub4(rnd_float3(seed), splat(0.5f)), cam->aperture));
+        dir = normalize4(sub4(focalPoint, O));
+        init_ray(r, O, dir);
+    } else { /* fisheye, camera.cl:25-44 */
+        float u = ((float)x - (float)W * .5f) * (2.f / (float)W);
+        float v = ((float)y - (float)H * .5f) * (2.f / (float)H);
+        if (aa) { u += rnd_float(seed) / (float)W; v += rnd_float(seed) / (float)H; }
+        float r2 = u * u + v * v;
+        if (r2 > 1.0f) { init_ray(r, splat(0.0f), splat(0.0f)); return; }
+        float rr = sqrtf(r2);
+        float psi = rr * cam->fov * 3.14159265358979323846f / 180.0f; /* r*fov*M_PI_F/180 */
+        float sinPsi = sinf(psi), cosPsi = cosf(psi);
+        float sinAlpha = u / rr, cosAlpha = v / rr;
+        f4 D = sub4(add4(muls(cam->up, sinPsi * cosAlpha), muls(cam->right, sinPsi * sinAlpha)), muls(cam->forward, cosPsi));
+        init_ray(r, cam->origin, D);
+    }
+}
+static void primary_ray_simple(RtRay* r, int x, int y, const RtCamera* cam, int W, int H) /* camera.cl:48-55 */
+{
+    float u = (float)x * (1.0f / (float)W);
+    float v = (float)y * (1.0f / (float)H);
+    f4 P = add4(add4(cam->topLeft, muls(cam->horizontal, u)), muls(cam->vertical, v));
+    init_ray(r, cam->origin, normalize4(sub4(P, cam->origin)));
+}
+
+/* ---------------------------------------------------------------- primitives (primitives.cl) */
+static void isect_sphere(int idx, const RtSphere* s, RtRay* ray) /* primitives.cl:11-30 */
+{
+    f4 oc = sub4(ray->O, s->pos);
+    float b = dot4(oc, ray->D);
+    float c = dot4(oc, oc) - s->r2;
+    float t, d = b * b - c;
+    if (d <= 0) return;
+    d = sqrtf(d); t = -b - d;
+    if (t < ray->t && t > 0) { ray->t = t; ray->primIdx = idx; return; }
+    t = d - b;
+    if (t < ray->t && t > 0) { ray->t = t; ray->primIdx = idx; return; }
+}
+static void isect_plane(int idx, const RtPlane* p, RtRay* ray) /* primitives.cl:32-44 */
+{
+    float t = -(dot4(ray->O, p->N) + p->d) / dot4(ray->D, p->N);
+    if (t > ray->t || t < 0) return;
+    ray->t = t; ray->primIdx = idx;
+    f4 uAxis = v4(p->N.y, p->N.z, -p->N.x, 0.0f);
+    f4 vAxis = cross4(uAxis, p->N);
+    f4 I = add4(ray->O, muls(ray->D, ray->t));
+    ray->u = dot4(I, uAxis); ray->v = dot4(I, vAxis);
+}
+static void isect_triangle(int idx, const RtTriangle* tri, RtRay* ray) /* primitives.cl:47-76 */
+{
+    f4 v0v1 = sub4(tri->v1, tri->v0);
+    f4 v0v2 = sub4(tri->v2, tri->v0);
+    f4 pvec = cross4(ray->D, v0v2);
+    float det = dot4(v0v1, pvec);
+    if (fabsf(det) < 1e-8f) return;
+    float invDet = 1.0f / det;
+    f4 tvec = sub4(ray->O, tri->v0);
+    float u = dot4(tvec, pvec) * invDet;
+    if (u < 0 || u > 1) return;
+    f4 qvec = cross4(tvec, v0v1);
+    float v = dot4(ray->D, qvec) * invDet;
+    if (v < 0 || u + v > 1) return;
+    float t = dot4(v0v2, qvec) * invDet;
+    if (t > ray->t || t < 0) return;
+    ray->t = t; ray->primIdx = idx; ray->u = u; ray->v = v;
+}
+static inline void isect_prim(int idx, const RtPrimitive* p, RtRay* ray) /* primitives.cl:78-89 */
+{
+    switch (p->objType) {
+    case RT_PRIM_SPHERE:   isect_sphere(idx, &p->obj.sphere, ray); break;
+    case RT_PRIM_PLANE:    isect_plane(idx, &p->obj.plane, ray); break;
+    case RT_PRIM_TRIANGLE: isect_triangle(idx, &p->obj.triangle, ray); break;
+    }
+}
+static f4 prim_normal(const RtPrimitive* p, f4 I) /* primitives.cl:91-105 */
+{
+    switch (p->objType) {
+    case RT_PRIM_SPHERE: return muls(sub4(I, p->obj.sphere.pos), p->obj.sphere.invr);
+    case RT_PRIM_PLANE:  return p->obj.plane.N;
+    default:             return p->obj.triangle.N;
+    }
+}
+static inline float fmod1(float x) { return fmodf(x, 1.f); }
+static f4 albedo_of(const RtRay* ray, const OrcScene* sc) /* primitives.cl:107-148 */
+{
+    const RtPrimitive* prim = &sc->prims[ray->primIdx];
+    const RtMaterial* mat = &sc->mats[prim->matIdx];
+    f4 albedo = mat->color;
+    if (mat->texIdx != -1) {
+        switch (prim->objType) {
+        case RT_PRIM_TRIANGLE: {
+            const RtTriangle* t = &prim->obj.triangle;
+            float w2 = 1 - ray->u - ray->v;
+            float ux = fmod1(ray->u * t->uv1.x + ray->v * t->uv0.x + w2 * t->uv2.x);
+            float uy = fmod1(ray->u * t->uv1.y + ray->v * t->uv0.y + w2 * t->uv2.y);
+            if (ux < 0) ux = 1 + ux;
+            if (uy < 0) uy = 1 + uy;
+            int x = (int)(ux * (float)mat->texW), y = (int)(uy * (float)mat->texH);
+            albedo = sc->tex[mat->texIdx + x + y * mat->texW];
+        } break;
+        case RT_PRIM_SPHERE: {
+            float ux = (float)((1 + atan2f(ray->N.z, ray->N.x) / 3.14159265358979323846) * 0.5); /* atan2pi, double 0.5 */
+            float uy = acosf(ray->N.y) / 3.14159265358979323846f;
+            int x = (int)(ux * (float)mat->texW), y = (int)(uy * (float)mat->texH);
+            albedo = sc->tex[mat->texIdx + x + y * mat->texW];
+        } break;
+        case RT_PRIM_PLANE: {
+            float u = fmod1(ray->u), v = fmod1(ray->v);
+            if (u < 0) u = 1 - u;
+            if (v < 0) v = 1 - v;
+            int x = (int)(u * (float)mat->texW), y = (int)(v * (float)mat->texH);
+            albedo = sc->tex[mat->texIdx + (x + y * mat->texW)];
+        } break;
+        }
+    }
+    return albedo;
+}
+static inline float survival_prob(f4 a) /* primitives.cl:150-153 */
+{
+    return fminf(fmaxf(fmaxf(a.x, fmaxf(a.y, a.z)), 0.f), 1.f);
+}
+static f4 random_point_on(const RtPrimitive* p, uint32_t* seed) /* primitives.cl:155-189 */
+{
+    if (p->objType == RT_PRIM_SPHERE) {
+        const RtSphere* s = &p->obj.sphere;
+        float theta = rnd_abs(seed) * 2.0f * 3.14159265358979323846f;
+        float u = rnd_abs(seed) * 2.0f - 1.0f;
+        float pre = sqrtf(1 - u * u);
+        float x = cosf(theta) * pre, y = sinf(theta) * pre;
+        return add4(muls(v4(x, y, u, 0.0f), s->r), s->pos);
+    }
+    const RtTriangle* t = &p->obj.triangle;
+    float u1 = rnd_abs(seed), u2 = rnd_abs(seed);
+    if (u1 + u2 > 1) { u1 = 1 - u1; u2 = 1 - u2; }
+    f4 a = sub4(t->v1, t->v0), b = sub4(t->v2, t->v0);
+    return add4(add4(t->v0, muls(a, u1)), muls(b, u2));
+}
+
+/* ---------------------------------------------------------------- traversal (bvh.cl, tlas.cl) */
+static inline float isect_aabb(const RtRay* ray, f4 bmin, f4 bmax) /* bvh.cl:3-12 */
+{
+    float tx1 = (bmin.x - ray->O.x) * ray->rD.x, tx2 = (bmax.x - ray->O.x) * ray->rD.x;
+    float tmin = fminf(tx1, tx2), tmax = fmaxf(tx1, tx2);
+    float ty1 = (bmin.y - ray->O.y) * ray->rD.y, ty2 = (bmax.y - ray->O.y) * ray->rD.y;
+    tmin = fmaxf(tmin, fminf(ty1, ty2)); tmax = fminf(tmax, fmaxf(ty1, ty2));
+    float tz1 = (bmin.z - ray->O.z) * ray->rD.z, tz2 = (bmax.z - ray->O.z) * ray->rD.z;
+    tmin = fmaxf(tmin, fminf(tz1, tz2)); tmax = fminf(tmax, fmaxf(tz1, tz2));
+    if (tmax >= tmin && tmin < ray->t && tmax > 0) return tmin;
+    return RT_REALLYFAR;
+}
+static int traverse_bvh2(RtRay* ray, const OrcScene* sc, uint32_t root, int occlusion, OrcCounters* c) /* bvh.cl:13-54 */
+{
+    const RtBVHNode2* nodes = sc->bvh2;
+    const RtBVHNode2* stack[RT_BVH2_STACK];
+    const RtBVHNode2* node = nodes + root;
+    uint32_t sp = 0; int steps = 0;
+    float t_light = ray->t;
+    for (;;) {
+        if (node->count > 0) {
+            for (uint32_t i = 0; i < node->count; i++) {
+                int index = (int)sc->primIdx[node->first + i];
+                c->prim_tests++;
+                isect_prim(index, &sc->prims[index], ray);
+                if (occlusion && ray->t < t_light) return -1;
+            }
+            if (sp == 0) break;
+            node = stack[--sp];
+            continue;
+        }
+        c->node_visits++;
+        const RtBVHNode2* c1 = &nodes[node->first];
+        const RtBVHNode2* c2 = &nodes[node->first + 1];
+        float d1 = isect_aabb(ray, c1->aabbMin, c1->aabbMax);
+        float d2 = isect_aabb(ray, c2->aabbMin, c2->aabbMax);
+        if (d1 > d2) { float d = d1; d1 = d2; d2 = d; const RtBVHNode2* t = c1; c1 = c2; c2 = t; }
+        if (d1 >= t_light) {
+            if (sp == 0) break;
+            node = stack[--sp];
+        } else {
+            steps++;
+            node = c1;
+            if (d2 < t_light) { stack[sp++] = c2; steps++; }
+        }
+    }
+    return steps;
+}
+static int traverse_bvh4(RtRay* ray, const OrcScene* sc, uint32_t root, int occlusion, OrcCounters* c) /* bvh.cl:55-96 */
+{
+    const RtBVHNode4* nodes = sc->bvh4;
+    const RtBVHNode4* stack[RT_BVH4_STACK];
+    const RtBVHNode4* node = nodes + root;
+    uint32_t sp = 0; int steps = 0;
+    float light_t = ray->t;
+    for (;;) {
+        steps++; c->node_visits++;
+        float dist[4];
+        for (int k = 0; k < 4; k++)
+            dist[k] = node->first[k] != RT_INVALID ? isect_aabb(ray, node->aabbMin[k], node->aabbMax[k]) : RT_REALLYFAR;
+        for (int k = 0; k < 4; k++) {
+            if (node->first[k] == RT_INVALID) continue;
+            if (dist[k] >= light_t) continue;
+            if (node->count[k] > 0) {
+                for (uint32_t j = 0; j < (uint32_t)node->count[k]; j++) {
+                    int index = (int)sc->primIdx[node->first[k] + j];
+                    c->prim_tests++;
+                    isect_prim(index, &sc->prims[index], ray);
+                    if (occlusion && ray->t < light_t) return -1;
+                }
+            } else {
+                stack[sp++] = nodes + node->first[k];
+            }
+        }
+        if (sp == 0) break;
+        node = stack[--sp];
+    }
+    return steps;
+}
+static inline f4 xform_vec(f4 V, const float* T) /* util.cl:61-73 */
+{
+    return v4(dot3(v4(T[0], T[1], T[2], 0), V), dot3(v4(T[4], T[5], T[6], 0), V), dot3(v4(T[8], T[9], T[10], 0), V), 0.0f);
+}
+static inline f4 xform_pos(f4 V, const float* T) /* util.cl:75-87 */
+{
+    return v4(dot3(v4(T[0], T[1], T[2], 0), V) + T[3], dot3(v4(T[4], T[5], T[6], 0), V) + T[7],
+              dot3(v4(T[8], T[9], T[10], 0), V) + T[11], 0.0f);
+}
+static int traverse_instance(RtRay* ray, const OrcScene* sc, const OrcConfig* cfg, const RtBVHInstance* inst, int occlusion, OrcCounters* c) /* tlas.cl:3-26 */
+{
+    f4 bO = ray->O, bD = ray->D, brD = ray->rD;
+    float T[16]; memcpy(T, inst->invT, sizeof T);
+    ray->D = xform_vec(bD, T);
+    ray->O = xform_pos(bO, T);
+    ray->rD = v4(1.0f / ray->D.x, 1.0f / ray->D.y, 1.0f / ray->D.z, 1.0f);
+    c->inst_visits++;
+    int steps = cfg->accel == ORC_ACCEL_BVH4 ? traverse_bvh4(ray, sc, inst->bvhIdx, occlusion, c)
+                                             : traverse_bvh2(ray, sc, inst->bvhIdx, occlusion, c);
+    ray->D = bD; ray->O = bO; ray->rD = brD;
+    return steps;
+}
+static int traverse_tlas(RtRay* ray, const OrcScene* sc, const OrcConfig* cfg, int occlusion, OrcCounters* c) /* tlas.cl:28-77 */
+{
+    const RtTLASNode* node = &sc->tlas[0];
+    const RtTLASNode* stack[RT_TLAS_STACK];
+    uint32_t sp = 0; int steps = 0;
+    float t_light = ray->t;
+    c->rays++;
+    for (;;) {
+        if (node->leftRight == 0) {
+            int value = traverse_instance(ray, sc, cfg, &sc->blas[node->BLASidx], occlusion, c);
+            if (occlusion && value == -1) return -1;
+            steps += value;
+            if (sp == 0) break;
+            node = stack[--sp];
+            continue;
+        }
+        c->tlas_visits++;
+        const RtTLASNode* c1 = &sc->tlas[node->leftRight & 0xffff];
+        const RtTLASNode* c2 = &sc->tlas[node->leftRight >> 16];
+        float d1 = isect_aabb(ray, c1->aabbMin, c1->aabbMax);
+        float d2 = isect_aabb(ray, c2->aabbMin, c2->aabbMax);
+        if (d1 > d2) { float d = d1; d1 = d2; d2 = d; const RtTLASNode* t = c1; c1 = c2; c2 = t; }
+        if (d1 >= t_light) {
+            if (sp == 0) break;
+            node = stack[--sp];
+        } else {
+            node = c1;
+            if (d2 < t_light) stack[sp++] = c2;
+        }
+    }
+    return steps;
+}
+
+/* ---------------------------------------------------------------- glass (glass.cl) */
+static float fresnel(RtRay* ray, const RtMaterial* mat, f4* outT) /* glass.cl:4-49 */
+{
+    float costhetai = dot4(ray->N, muls(ray->D, -1.0f));
+    float n1 = mat->n1, n2 = mat->n2;
+    if (ray->inside) {
+        n1 = mat->n2; n2 = mat->n1;
+        ray->intensity.x *= expf(-mat->absorption.x * ray->t); /* beersLaw, glass.cl:4-9 */
+        ray->intensity.y *= expf(-mat->absorption.y * ray->t);
+        ray->intensity.z *= expf(-mat->absorption.z * ray->t);
+    }
+    float frac = n1 * (1 / n2);
+    float k = 1 - frac * frac * (1 - costhetai * costhetai);
+    if (k < 0) return 1.f;
+    *outT = normalize4(add4(muls(ray->D, frac), muls(ray->N, frac * costhetai - sqrtf(k))));
+    float costhetat = dot4(neg4(ray->N), *outT);
+    float n1ci = n1 * costhetai, n2ci = n2 * costhetai, n1ct = n1 * costhetat, n2ct = n2 * costhetat;
+    float frac1 = (n1ci - n2ct) / (n1ci + n2ct);
+    float frac2 = (n1ct - n2ci) / (n1ct + n2ci);
+    float Fr = 0.5f * (frac1 * frac1 + frac2 * frac2);
+    return mat->specular + (1 - mat->specular) * Fr;
+}
+
+/* ---------------------------------------------------------------- shading (shading.cl) */
+#define PI_F   3.14159274101257f   /* M_PI_F   */
+#define INVPI_F 0.31830987334251f  /* M_1_PI_F */
+
+static f4 sample_dir(f4 N, uint32_t* seed, const OrcConfig* cfg)
+{
+    return cfg->sampling == ORC_SAMPLING_HEMISPHERE ? random_ray_hemisphere(N, seed) : cosine_ray_hemisphere(N, seed);
+}
+static f4 shade_kajiya(RtRay* ray, RtRay* ext, uint32_t* seed, const OrcScene* sc, const OrcConfig* cfg) /* shading.cl:7-70 */
+{
+    const RtPrimitive* prim = &sc->prims[ray->primIdx];
+    const RtMaterial* mat = &sc->mats[prim->matIdx];
+    if (mat->isLight) return mul4(ray->intensity, mat->emittance);
+    RtRay r;
+    float rnd = rnd_float(seed);
+    if (mat->isDielectric) {
+        f4 T = splat(0.0f);
+        float Fr = fresnel(ray, mat, &T);
+        r = rnd < Fr ? reflect_ray(ray) : transmit_ray(ray, T);
+    } else if (rnd < mat->specular) {
+        r = reflect_ray(ray);
+    } else {
+        f4 albedo = albedo_of(ray, sc);
+        if (cfg->russian_roulette) {
+            float rr_p = survival_prob(albedo);
+            if (rr_p < rnd_float(seed)) return splat(0.0f);
+            ray->intensity = muls(ray->intensity, 1 / rr_p);
+        }
+        f4 refl = sample_dir(ray->N, seed, cfg);
+        float dotNR = dot4(ray->N, refl);
+        float I_PDF = cfg->sampling == ORC_SAMPLING_HEMISPHERE ? 2 * PI_F : dotNR * PI_F;
+        f4 BRDF = muls(albedo, INVPI_F);
+        ray->intensity = mul4(ray->intensity, muls(muls(BRDF, I_PDF), dotNR)); /* intensity *= (BRDF*I_PDF)*dotNR */
+        r = zero_ray(); init_ray(&r, add4(ray->I, muls(refl, RT_EPSILON)), refl);
+        r.intensity = ray->intensity; r.bounces = ray->bounces + 1; r.inside = ray->inside;
+    }
+    r.pixelIdx = ray->pixelIdx;
+    *ext = r;
+    return splat(0.0f);
+}
+static f4 shade_nee(RtRay* ray, RtRay* ext, RtShadowRay* shadow, uint32_t* seed, const OrcScene* sc, const OrcConfig* cfg) /* shading.cl:72-169 */
+{
+    const RtPrimitive* prim = &sc->prims[ray->primIdx];
+    const RtMaterial* mat = &sc->mats[prim->matIdx];
+    if (mat->isLight) return ray->lastSpecular ? mul4(ray->intensity, mat->emittance) : splat(0.0f);
+    RtRay r;
+    float rnd = rnd_float(seed);
+    if (mat->isDielectric) {
+        f4 T = splat(0.0f);
+        float Fr = fresnel(ray, mat, &T);
+        r = rnd < Fr ? reflect_ray(ray) : transmit_ray(ray, T);
+        r.lastSpecular = 1;
+    } else if (rnd < mat->specular) {
+        r = reflect_ray(ray);
+        r.lastSpecular = 1;
+    } else {
+        f4 albedo = albedo_of(ray, sc);
+        f4 BRDF = muls(albedo, INVPI_F);
+        if (sc->nLights > 0) {
+            /* reference reads lights[numLights] when the draw is exactly 1.0 (out of bounds,
+             * probability 2^-25 per draw); both this oracle and the HIP path clamp instead. */
+            uint32_t li = (uint32_t)floorf(rnd_abs(seed) * (float)sc->nLights);
+            if (li >= (uint32_t)sc->nLights) li = (uint32_t)sc->nLights - 1;
+            uint32_t lightIdx = sc->lights[li];
+            const RtPrimitive* lp = &sc->prims[lightIdx];
+            f4 pl = random_point_on(lp, seed);
+            f4 dirToLight = sub4(pl, ray->I);
+            f4 Nl = prim_normal(lp, pl);
+            float dist = length4(dirToLight);
+            f4 L = muls(dirToLight, 1 / dist);
+            float dotNL = dot4(ray->N, L);
+            if (dotNL > 0 && dot4(Nl, neg4(L)) > 0) {
+                shadow->I = ray->I; shadow->L = L; shadow->Nl = Nl;
+                shadow->intensity = muls(ray->intensity, (float)sc->nLights);
+                shadow->BRDF = BRDF; shadow->lightIdx = (int32_t)lightIdx; shadow->pixelIdx = ray->pixelIdx;
+                shadow->dotNL = dotNL; shadow->dist = dist;
+            }
+        }
+        if (cfg->russian_roulette) {
+            float rr_p = survival_prob(albedo);
+            if (rr_p < rnd_float(seed)) return splat(0.0f);
+            ray->intensity = muls(ray->intensity, 1 / rr_p);
+        }
+        f4 refl = sample_dir(ray->N, seed, cfg);
+        float dotNR = dot4(ray->N, refl);
+        float I_PDF = cfg->sampling == ORC_SAMPLING_HEMISPHERE ? 2 * PI_F : dotNR * PI_F;
+        r = zero_ray(); init_ray(&r, add4(ray->I, muls(refl, RT_EPSILON)), refl);
+        r.intensity = muls(muls(mul4(ray->intensity, BRDF), I_PDF), dotNR); /* ((intensity*BRDF)*I_PDF)*dotNR */
+        r.bounces = ray->bounces + 1; r.inside = ray->inside;
+    }
+    r.pixelIdx = ray->pixelIdx;
+    *ext = r;
+    return splat(0.0f);
+}
+static inline f4 firefly(f4 c, const OrcConfig* cfg) /* wavefront.cl:125-127,196-198 */
+{
+    if (cfg->filter_fireflies && dot4(c, c) > 25) return muls(normalize4(c), 5.0f);
+    return c;
+}
+
+/* ---------------------------------------------------------------- kernels (wavefront.cl) */
+void orc_generate(RtRay* rays, int32_t n, int32_t firstPixel, const OrcConfig* cfg, const RtCamera* cam,
+                  int32_t aa, uint32_t* seeds) /* wavefront.cl:14-34 */
+{
+    for (int32_t i = 0; i < n; i++) {
+        int32_t idx = firstPixel + i;
+        RtRay r = zero_ray();
+        primary_ray(&r, idx % cfg->width, idx / cfg->width, cam, aa, cfg->width, cfg->height, &seeds[i]);
+        r.lastSpecular = 1; r.pixelIdx = idx;
+        rays[i] = r;
+    }
+}
+static void finish_hit(RtRay* ray, const OrcScene* sc) /* wavefront.cl:68-72 */
+{
+    if (ray->primIdx == -1) return;
+    ray->I = add4(ray->O, muls(ray->D, ray->t));
+    ray->N = prim_normal(&sc->prims[ray->primIdx], ray->I);
+    if (dot4(ray->N, neg4(ray->D)) < 0) ray->N = muls(ray->N, -1.0f);
+}
+void orc_extend(RtRay* rays, int32_t n, const OrcScene* sc, const OrcConfig* cfg, int32_t renderBVH,
+                RtFloat4* accum, int32_t* stepsOut, OrcCounters* ctr) /* wavefront.cl:35-75 */
+{
+    OrcCounters local; memset(&local, 0, sizeof local);
+    for (int32_t idx = 0; idx < n; idx++) {
+        RtRay* ray = &rays[idx];
+        int steps = traverse_tlas(ray, sc, cfg, 0, &local);
+        if (stepsOut) stepsOut[idx] = steps;
+        if (renderBVH && accum) accum[idx] = splat((float)(uint32_t)steps / 255.f);
+        finish_hit(ray, sc);
+    }
+    if (ctr) { ctr->rays += local.rays; ctr->tlas_visits += local.tlas_visits; ctr->inst_visits += local.inst_visits;
+               ctr->node_visits += local.node_visits; ctr->prim_tests += local.prim_tests; }
+}
+void orc_shade(RtRay* in, int32_t nIn, RtRay* out, int32_t* nOut, RtShadowRay* shadow, int32_t* nShadow,
+               const OrcScene* sc, const OrcConfig* cfg, RtFloat4* accum, uint32_t* seeds) /* wavefront.cl:76-142 */
+{
+    const f4 sky = v4(0.0784f, 0.0941f, 0.3215f, 0.0f); /* skydome.cl:7 */
+    int s0 = cfg->schedule == ORC_SCHED_S0;
+    for (int32_t k = 0; k < nIn; k++) {
+        int32_t idx = s0 ? nIn - 1 - k : k;
+        uint32_t* seed = s0 ? &seeds[0] : &seeds[idx];
+        RtRay* ray = &in[idx];
+        if (ray->primIdx == -1) {
+            accum[ray->pixelIdx] = add4(accum[ray->pixelIdx], mul4(ray->intensity, sky));
+            continue;
+        }
+        RtRay ext = zero_ray(); init_ray(&ext, splat(0.0f), splat(0.0f));
+        ext.bounces = RT_MAX_BOUNCES + 1;
+        RtShadowRay sr; memset(&sr, 0, sizeof sr); sr.pixelIdx = -1;
+        f4 color = cfg->shading == ORC_SHADING_SIMPLE ? shade_kajiya(ray, &ext, seed, sc, cfg)
+                                                      : shade_nee(ray, &ext, &sr, seed, sc, cfg);
+        color = firefly(color, cfg);
+        accum[ray->pixelIdx] = add4(accum[ray->pixelIdx], color);
+        if (ext.bounces <= RT_MAX_BOUNCES) out[(*nOut)++] = ext;
+        if (cfg->shading == ORC_SHADING_NEE && sr.pixelIdx != -1) shadow[(*nShadow)++] = sr;
+    }
+}
+void orc_connect(const RtShadowRay* shadow, int32_t n, const OrcScene* sc, const OrcConfig* cfg,
+                 RtFloat4* accum, OrcCounters* ctr) /* wavefront.cl:144-201 */
+{
+    OrcCounters local; memset(&local, 0, sizeof local);
+    int s0 = cfg->schedule == ORC_SCHED_S0;
+    for (int32_t k = 0; k < n; k++) {
+        const RtShadowRay* s = &shadow[s0 ? n - 1 - k : k];
+        RtRay ray = zero_ray();
+        init_ray(&ray, add4(s->I, muls(s->L, RT_EPSILON)), s->L);
+        ray.t = s->dist - 2 * RT_EPSILON;
+        if (traverse_tlas(&ray, sc, cfg, 1, &local) == -1) continue;
+        const RtPrimitive* lp = &sc->prims[s->lightIdx];
+        float solidAngle = dot4(s->Nl, neg4(s->L)) * lp->area * (1 / (s->dist * s->dist));
+        f4 lightColor = sc->mats[lp->matIdx].emittance;
+        f4 Ld = muls(mul4(muls(lightColor, solidAngle), s->BRDF), s->dotNL);
+        f4 color = firefly(mul4(Ld, s->intensity), cfg);
+        accum[s->pixelIdx] = add4(accum[s->pixelIdx], color);
+    }
+    if (ctr) { ctr->rays += local.rays; ctr->tlas_visits += local.tlas_visits; ctr->inst_visits += local.inst_visits;
+               ctr->node_visits += local.node_visits; ctr->prim_tests += local.prim_tests; }
+}
+float orc_focus(int32_t x, int32_t y, const OrcScene* sc, const OrcConfig* cfg, const RtCamera* cam) /* wavefront.cl:203-224 */
+{
+    RtRay r = zero_ray(); OrcCounters c; memset(&c, 0, sizeof c);
+    primary_ray_simple(&r, x, y, cam, cfg->width, cfg->height);
+    traverse_tlas(&r, sc, cfg, 0, &c);
+    return r.t;
+}
+
+/* ---------------------------------------------------------------- frame driver (renderer.cpp:64-94) */
+size_t orc_frame_work_bytes(int32_t n, const OrcConfig* cfg)
+{
+    return (size_t)n * (2 * sizeof(RtRay) + (size_t)(cfg->max_bounces > 0 ? cfg->max_bounces : 1) * sizeof(RtShadowRay));
+}
+void orc_render_frame(const OrcScene* sc, const OrcConfig* cfg, const RtCamera* cam, int32_t aa,
+                      int32_t firstPixel, int32_t n, RtFloat4* accum, uint32_t* seeds, void* work,
+                      OrcCounters* extendCtr, OrcCounters* connectCtr)
+{
+    RtRay* ray1 = (RtRay*)work;
+    RtRay* ray2 = ray1 + n;
+    RtShadowRay* shadow = (RtShadowRay*)(ray2 + n);
+    int32_t nIn = n, nShadow = 0;
+    orc_generate(ray1, n, firstPixel, cfg, cam, aa, seeds);
+    for (int b = 0; b < cfg->max_bounces; b++) {
+        orc_extend(ray1, nIn, sc, cfg, 0, NULL, NULL, extendCtr);
+        int32_t nOut = 0;
+        orc_shade(ray1, nIn, ray2, &nOut, shadow, &nShadow, sc, cfg, accum, seeds);
+        if (!cfg->russian_roulette && cfg->shading == ORC_SHADING_NEE) { /* renderer.cpp:85-87 */
+            orc_connect(shadow, nShadow, sc, cfg, accum, connectCtr);
+            nShadow = 0;                                                  /* wavefront.cl:54-56 */
+        }
+        RtRay* t = ray1; ray1 = ray2; ray2 = t;
+        nIn = nOut;
+    }
+    if (cfg->russian_roulette) orc_connect(shadow, nShadow, sc, cfg, accum, connectCtr); /* renderer.cpp:91-92 */
+}
+
+static void add_ctr(OrcCounters* d, const OrcCounters* s)
+{
+    if (!d) return;
+    d->rays += s->rays; d->tlas_visits += s->tlas_visits; d->inst_visits += s->inst_visits;
+    d->node_visits += s->node_visits; d->prim_tests += s->prim_tests;
+}
+void orc_render_bands(const OrcScene* sc, const OrcConfig* cfg, const RtCamera* cam, int32_t aa,
+                      int32_t y0, int32_t y1, int32_t frames, int32_t threads, RtFloat4* accum, uint32_t* seeds,
+                      OrcCounters* extendCtr, OrcCounters* connectCtr)
+{
+    if (threads < 1) threads = 1;
+    int rows = y1 - y0;
+    if (threads > rows) threads = rows;
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+    for (int b = 0; b < threads; b++) {
+        int r0 = y0 + (int)((int64_t)rows * b / threads), r1 = y0 + (int)((int64_t)rows * (b + 1) / threads);
+        int32_t first = r0 * cfg->width, n = (r1 - r0) * cfg->width;
+        void* work = malloc(orc_frame_work_bytes(n, cfg));
+        OrcCounters e, c; memset(&e, 0, sizeof e); memset(&c, 0, sizeof c);
+        for (int f = 0; f < frames; f++)
+            orc_render_frame(sc, cfg, cam, aa, first, n, accum, seeds + (first - y0 * cfg->width), work, &e, &c);
+        free(work);
+#pragma omp critical
+        { add_ctr(extendCtr, &e); add_ctr(connectCtr, &c); }
+    }
+}
+void orc_trace_normals(const OrcScene* sc, const OrcConfig* cfg, const RtCamera* cam, int32_t threads, RtFloat4* out)
+{
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 4)
+    for (int y = 0; y < cfg->height; y++) {
+        OrcCounters c; memset(&c, 0, sizeof c);
+        for (int x = 0; x < cfg->width; x++) {
+            RtRay r = zero_ray();
+            primary_ray_simple(&r, x, y, cam, cfg->width, cfg->height);
+            traverse_tlas(&r, sc, cfg, 0, &c);
+            finish_hit(&r, sc);
+            out[y * cfg->width + x] = r.primIdx == -1 ? splat(0.0f)
+                : muls(add4(r.N, splat(1.0f)), 0.5f);
+        }
+    }
+}
