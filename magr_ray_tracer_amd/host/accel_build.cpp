@@ -165,6 +165,17 @@ void BVH2::BuildBVH(uint32_t root, Refs data)
         Refs left, right;
         if (objectCost < spatialCost) ObjectSplit(objectAxis, objectPos, refs, left, right);
         else { stat_spatial_splits++; SpatialSplit(spatialAxis, spatialPos, refs, left, right); }
+        // Termination guard (deviation from the reference, which recurses without bound here): a
+        // spatial split that hands every reference to one child or duplicates all of them into both
+        // makes no progress and would be chosen again for the child -> close the node as a leaf.
+        if (left.empty() || right.empty() || (left.size() >= refs.size() && right.size() >= refs.size())) {
+            RtBVHNode2& n = bvhNodes[nodeIdx];
+            n.first = (uint32_t)primIdx.size();
+            n.count = (uint32_t)refs.size();
+            for (const BVHPrimData& r : refs) primIdx.push_back(r.idx);
+            stat_forced_leaves++;
+            continue;
+        }
         uint32_t leftId = nodesUsed_++, rightId = nodesUsed_++;
         UpdateNodeBounds(leftId, left);
         UpdateNodeBounds(rightId, right);

@@ -67,7 +67,7 @@ public:
     std::vector<RtBVHNode2> bvhNodes;
     std::vector<uint32_t>   primIdx;
     float    alpha = 1.f;
-    uint32_t stat_depth = 0, stat_node_count = 0, stat_spatial_splits = 0, stat_prims_clipped = 0, stat_prim_count = 0;
+    uint32_t stat_depth = 0, stat_node_count = 0, stat_spatial_splits = 0, stat_prims_clipped = 0, stat_prim_count = 0, stat_forced_leaves = 0;
     float    stat_sah_cost = 0, stat_build_time = 0;
     std::vector<RtBVHInstance>& blasNodes;
 private:

@@ -695,3 +695,24 @@ void orc_trace_normals(const OrcScene* sc, const OrcConfig* cfg, const RtCamera*
         }
     }
 }
+
+/* ---------------------------------------------------------------- unit hooks for the known-answer tests */
+void orc_test_random_float3(uint32_t* seed, float out[4]) { f4 r = rnd_float3(seed); out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w; }
+void orc_test_cosine_hemisphere(const float N[4], uint32_t* seed, float out[4])
+{
+    f4 r = cosine_ray_hemisphere(v4(N[0], N[1], N[2], N[3]), seed);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+void orc_test_triangle(const float v0[3], const float v1[3], const float v2[3], const float O[3], const float D[3], float out[4])
+{
+    RtTriangle t; memset(&t, 0, sizeof t);
+    t.v0 = v4(v0[0], v0[1], v0[2], 0); t.v1 = v4(v1[0], v1[1], v1[2], 0); t.v2 = v4(v2[0], v2[1], v2[2], 0);
+    RtRay r = zero_ray(); init_ray(&r, v4(O[0], O[1], O[2], 0), v4(D[0], D[1], D[2], 0));
+    isect_triangle(7, &t, &r);
+    out[0] = r.t; out[1] = r.u; out[2] = r.v; out[3] = (float)r.primIdx;
+}
+uint32_t orc_test_wang_hash(uint32_t s) /* util.cl:37-44 (unused on the path; known answer WangHash(1)) */
+{
+    s = (s ^ 61) ^ (s >> 16); s *= 9; s = s ^ (s >> 4); s *= 0x27d4eb2d; s = s ^ (s >> 15);
+    return s;
+}

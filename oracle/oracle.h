@@ -97,6 +97,12 @@ void orc_render_bands(const OrcScene* sc, const OrcConfig* cfg, const RtCamera* 
 void orc_trace_normals(const OrcScene* sc, const OrcConfig* cfg, const RtCamera* cam,
                        int32_t threads, RtFloat4* out);
 
+/* Unit hooks for the known-answer tests. */
+void     orc_test_random_float3(uint32_t* seed, float out[4]);
+void     orc_test_cosine_hemisphere(const float N[4], uint32_t* seed, float out[4]);
+void     orc_test_triangle(const float v0[3], const float v1[3], const float v2[3], const float O[3], const float D[3], float out[4]);
+uint32_t orc_test_wang_hash(uint32_t s);
+
 #ifdef __cplusplus
 }
 #endif

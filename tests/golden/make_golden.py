@@ -1,0 +1,69 @@
+"""Generates tests/golden/ref_*.npz ON THE GPU BOX by running the REFERENCE's own OpenCL kernels
+(oracle/_ref/*.co, compiled from /root/reference by oracle/build_ref.sh; nothing of the reference's
+source is stored here).  Each fixture holds the inputs (scene arrays, camera, seeds) and the reference's
+outputs per stage:  generate -> extend -> shade (one work-item = schedule S0) -> connect (S0).
+
+    gpurun -- python tests/golden/make_golden.py gpurun_out/golden     # then copy the .npz into tests/golden/
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from magr_ray_tracer_amd import scenes  # noqa: E402
+from oracle.oracle_py import seed_stream  # noqa: E402
+from ref_gpu import REF_H, REF_W, RefGPU  # noqa: E402
+
+CASES = {
+    # name: (scene factory, view override, rows, variant)
+    "mixed_nee": (lambda: scenes.mixed_scene(textured=True), dict(forward=(0.32, 0.75, 0.92)), 4, dict()),
+    "mixed_kajiya_hemi": (lambda: scenes.mixed_scene(textured=True), dict(forward=(0.32, 0.75, 0.92)), 4,
+                          dict(shading=0, sampling=0, russian_roulette=False, filter_fireflies=False)),
+    "cube_nee_bvh4": (scenes.cube_scene, dict(forward=(0.5, 0.9, 0.82)), 4, dict(accel=1)),
+    "twoblas_nee": (lambda: scenes.two_blas_scene(alpha=0.0, n=10), dict(forward=(0.02, 0.8, 0.97)), 4, dict()),
+}
+VKEYS = ("shading", "sampling", "accel", "russian_roulette", "filter_fireflies")
+VDEF = dict(shading=1, sampling=1, accel=0, russian_roulette=True, filter_fireflies=True)
+
+
+def make(name, outdir):
+    fn, vo, rows, variant = CASES[name]
+    variant = dict(VDEF, **variant)
+    s, view = fn()
+    view = dict(view, **vo)
+    sa = s.arrays()
+    cam = scenes.camera_for(view, REF_W, REF_H)
+    ref = RefGPU(sa, **variant)
+    cam["focalLength"] = ref.focus(REF_W // 2, rows // 2, cam)
+    n = REF_W * rows
+    seeds_in = seed_stream(0, n)
+    gen_rays, gen_seeds = ref.generate(cam, seeds_in)
+    ext_rays = ref.extend(gen_rays)
+    ref.clear_accum()
+    shade_rays, shade_shadow, shade_seeds = ref.shade_s0(ext_rays, gen_seeds)
+    shade_accum = ref.read_accum(rows)
+    ref.clear_accum()
+    if len(shade_shadow):
+        ref.connect_s0(shade_shadow)
+    connect_accum = ref.read_accum(rows)
+    ref.close()
+    path = os.path.join(outdir, f"ref_{name}.npz")
+    np.savez_compressed(
+        path, prims=sa.prims, mats=sa.mats, tex=sa.tex, lights=sa.lights, bvh2=sa.bvh2, bvh4=sa.bvh4, primIdx=sa.primIdx,
+        tlas=sa.tlas, blas=sa.blas, cam=np.ascontiguousarray(cam).reshape(1).view(np.uint8), seeds_in=seeds_in,
+        variant=np.array([int(variant[k]) for k in VKEYS], np.int32), dims=np.array([REF_W, REF_H, n, rows], np.int32),
+        gen_rays=gen_rays.view(np.uint8), gen_seeds=gen_seeds, ext_rays=ext_rays.view(np.uint8),
+        shade_rays=shade_rays.view(np.uint8), shade_shadow=shade_shadow.view(np.uint8), shade_seeds=shade_seeds[:4],
+        shade_accum=shade_accum, connect_accum=connect_accum)
+    print(name, "rays", n, "hits", int((ext_rays["primIdx"] != -1).sum()), "ext", len(shade_rays), "shadow", len(shade_shadow),
+          "->", path, os.path.getsize(path) // 1024, "KiB", flush=True)
+
+
+if __name__ == "__main__":
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "golden")
+    os.makedirs(out, exist_ok=True)
+    for name in CASES:
+        make(name, out)

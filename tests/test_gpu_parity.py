@@ -1,0 +1,322 @@
+"""GPU parity suite (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle on the same
+seeded inputs.  Everything the path computes with IEEE + - * / sqrt and fma is required to be BIT-EXACT
+(accumulator, ray queues, RNG state, work counters); scenes that reach transcendentals (sphere lights,
+sphere textures, glass: sin/cos/acos/atan2/exp come from different math libraries) are held to the
+north star's 1e-4 relative per-pixel tolerance."""
+import numpy as np
+import pytest
+
+from magr_ray_tracer_amd import _lib as W, scenes
+from magr_ray_tracer_amd.renderer import Device, Renderer, RtError
+from oracle.oracle_py import Oracle, seed_stream
+from helpers import DEFAULT, assert_bits, bits_equal, build, max_rel
+
+pytestmark = pytest.mark.gpu
+
+TRI_SCENES = {
+    "cube": scenes.cube_scene,
+    "bunny32": lambda: scenes.bunny_class(32),
+    "sponza.2": lambda: scenes.sponza_class(0.2),
+}
+
+
+def _pair(scene_fn, Wd, Hd, variant, y0=0, y1=None):
+    s, sa, cam = build(scene_fn, Wd, Hd)
+    o = Oracle(sa, Wd, Hd, **variant)
+    d = Device(Wd, Hd, y0=y0, y1=y1, **variant)
+    d.upload(sa)
+    return sa, cam, o, d
+
+
+def _ctr_equal(dev, e, c):
+    for k in ("rays", "tlas_visits", "inst_visits", "node_visits", "prim_tests"):
+        assert dev["extend_" + k] == e[k], ("extend_" + k, dev["extend_" + k], e[k])
+        assert dev["connect_" + k] == c[k], ("connect_" + k, dev["connect_" + k], c[k])
+
+
+@pytest.mark.parametrize("scene", list(TRI_SCENES))
+def test_stage_by_stage_bit_exact(scene):
+    Wd, Hd = 96, 54
+    sa, cam, o, d = _pair(TRI_SCENES[scene], Wd, Hd, DEFAULT)
+    f = o.focus(Wd // 2, Hd // 2, cam)
+    assert d.focus(Wd // 2, Hd // 2, cam) == f
+    cam["focalLength"] = f
+    n = Wd * Hd
+    seeds = seed_stream(0, n)
+    d.set_seeds(seeds.copy())
+    acc = np.zeros((Hd * Wd, 4), np.float32)
+    d.reset()
+    d.stage_begin_frame()
+    d.stage_generate(cam)
+    rays = o.generate(cam, 0, n, seeds)
+    g = d.get_rays(0)
+    for fld in ("O", "D", "intensity", "pixelIdx", "bounces", "inside", "lastSpecular"):
+        assert_bits(g[fld], rays[fld], "generate " + fld)
+    assert np.array_equal(d.get_seeds(), seeds)
+    shadows = []
+    for b in range(W.MAX_BOUNCES):
+        steps, _ = o.extend(rays, want_steps=True)
+        d.stage_extend(b)
+        g = d.get_rays(b)
+        hit = rays["primIdx"] != -1
+        for fld in ("t", "primIdx", "I", "N"):
+            assert_bits(g[fld], rays[fld], f"extend{b} {fld}")
+        assert_bits(g["u"][hit], rays["u"][hit], f"extend{b} u")
+        assert_bits(g["v"][hit], rays["v"][hit], f"extend{b} v")
+        assert np.array_equal(d.get_steps()[:len(rays)], steps), f"extend{b} steps"   # the reference's own `steps` value
+        nxt, sh = o.shade(rays, acc, seeds)
+        d.stage_shade(b)
+        g = d.get_rays(b + 1)
+        assert len(g) == len(nxt), f"shade{b}: queue length {len(g)} vs {len(nxt)}"
+        for fld in ("O", "D", "intensity", "pixelIdx", "bounces", "inside", "lastSpecular"):
+            assert_bits(g[fld], nxt[fld], f"shade{b} {fld}")
+        assert np.array_equal(d.get_seeds(), seeds), f"shade{b} RNG state"
+        rec = d.get_shadow(b, b)
+        assert len(rec) == len(sh)
+        if len(sh):
+            eps = np.float32(1e-4)
+            assert_bits(rec["o"], (sh["I"] + sh["L"] * eps)[:, :3], f"shadow{b} origin")
+            assert_bits(rec["l"], sh["L"][:, :3], f"shadow{b} dir")
+            assert_bits(rec["tmax"], sh["dist"] - np.float32(2) * eps, f"shadow{b} tmax")
+            assert np.array_equal(rec["pixelIdx"], sh["pixelIdx"])
+        shadows.append(sh)
+        rays = nxt
+    o.connect(np.concatenate(shadows), acc)
+    d.stage_connect(0, W.MAX_BOUNCES - 1)
+    assert_bits(d.read_accum().reshape(-1, 4), acc, "accumulator")
+    d.close()
+
+
+VARIANTS = [
+    dict(),
+    dict(shading=0),
+    dict(shading=0, sampling=0, russian_roulette=False, filter_fireflies=False),
+    dict(sampling=0),
+    dict(russian_roulette=False),
+    dict(filter_fireflies=False),
+    dict(accel=1),
+    dict(accel=1, shading=0),
+]
+
+
+@pytest.mark.parametrize("vi", range(len(VARIANTS)))
+def test_frames_bit_exact_all_variants(vi):
+    v = dict(DEFAULT, **VARIANTS[vi])
+    Wd, Hd, frames = 128, 72, 3
+    sa, cam, o, d = _pair(lambda: scenes.sponza_class(0.2), Wd, Hd, v)
+    cam["focalLength"] = o.focus(Wd // 2, Hd // 2, cam)
+    acc, seeds, e, c = o.render(cam, frames)
+    d.seed_default()
+    d.render(cam, frames)
+    assert_bits(d.read_accum(), acc, "accumulator")
+    assert np.array_equal(d.get_seeds(), seeds)
+    _ctr_equal(d.counters(), e, c)
+    assert acc[..., :3].sum() > 0
+    d.close()
+
+
+@pytest.mark.parametrize("alpha,accel", [(0.0, 0), (0.0, 1), (1e-5, 0)])
+def test_sbvh_and_tlas_two_blas(alpha, accel):
+    v = dict(DEFAULT, accel=accel)
+    Wd, Hd = 128, 72
+
+    def fn():
+        s, view = scenes.two_blas_scene(alpha=alpha, n=20)
+        return s, view
+    # the glass sphere reaches exp(): tolerance; a triangle-only TLAS scene follows bit-exact
+    sa, cam, o, d = _pair(fn, Wd, Hd, v)
+    assert len(sa.blas) == 2
+    acc, seeds, e, c = o.render(cam, 2)
+    d.seed_default()
+    d.render(cam, 2)
+    got = d.read_accum()
+    bad = np.abs(got - acc) > 1e-4 * np.maximum(np.abs(acc), 1e-3)
+    assert bad.mean() < 2e-3, f"{bad.sum()} pixels beyond 1e-4"
+    dc = d.counters()
+    assert dc["extend_tlas_visits"] > 0 and abs(dc["extend_node_visits"] - e["node_visits"]) <= 0.01 * e["node_visits"]
+    d.close()
+
+
+def test_tlas_triangles_only_bit_exact():
+    def fn():
+        from magr_ray_tracer_amd.scenes import Scene, _std_materials, param_surface, box_tris
+        s = Scene()
+        _std_materials(s)
+        s.AddTriangles(box_tris((-2, 0, -1), (-0.5, 1.5, 0.5)), "red")
+        s.AddQuad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6), "grey")
+        s.AddQuad((-1, 4, -1), (1, 4, -1), (1, 4, 1), (-1, 4, 1), "white-light")
+        s.BuildBLAS(0, 0.0)
+        st = s.num_prims
+        s.AddTriangles(box_tris((0.6, 0, -0.8), (2.0, 2.2, 0.8)), "mirror")
+        s.AddTriangles(box_tris((0.2, 2.6, -0.4), (1.0, 3.0, 0.4)), "green")
+        s.BuildBLAS(st, 0.0)
+        st = s.num_prims
+        s.AddTriangles(box_tris((-0.4, 0, 1.4), (0.4, 0.8, 2.2)), "sand")
+        s.BuildBLAS(st, 1.0)
+        return s, dict(origin=(0.5, 2.4, 6.0), forward=(0.05, 0.2, 0.97), fov=65.0, aperture=0.03)
+    for accel in (0, 1):
+        v = dict(DEFAULT, accel=accel)
+        sa, cam, o, d = _pair(fn, 128, 72, v)
+        assert len(sa.blas) == 3 and len(sa.tlas) == 6
+        acc, seeds, e, c = o.render(cam, 3)
+        d.seed_default()
+        d.render(cam, 3)
+        assert_bits(d.read_accum(), acc, f"accumulator accel={accel}")
+        _ctr_equal(d.counters(), e, c)
+        d.close()
+
+
+def test_all_primitive_and_material_kinds_within_tolerance():
+    """Spheres (diffuse/mirror/glass/emissive), textured triangles, two light kinds: reaches sin/cos/exp/acos/atan2."""
+    Wd, Hd, frames = 160, 90, 4
+    sa, cam, o, d = _pair(scenes.mixed_scene, Wd, Hd, DEFAULT)
+    cam["focalLength"] = o.focus(Wd // 2, Hd // 2, cam)
+    acc, seeds, e, c = o.render(cam, frames)
+    d.seed_default()
+    d.render(cam, frames)
+    got = d.read_accum()
+    rel = np.abs(got - acc) / np.maximum(np.abs(acc), 1e-3)
+    assert (rel > 1e-4).mean() < 1e-3, f"{(rel > 1e-4).sum()} of {rel.size} beyond 1e-4 relative"
+    assert np.array_equal(d.get_seeds(), seeds) or (d.get_seeds() != seeds).mean() < 1e-3
+    d.close()
+
+
+def test_row_band_matches_oracle_band():
+    v = DEFAULT
+    Wd, Hd = 128, 72
+    sa, cam, o, d = _pair(lambda: scenes.sponza_class(0.2), Wd, Hd, v, y0=24, y1=48)
+    acc, seeds, e, c = o.render(cam, 2, y0=24, y1=48)
+    d.seed_default()
+    d.render(cam, 2)
+    got = d.read_accum()
+    assert_bits(got, acc, "band accumulator")
+    assert not got[:24].any() and not got[48:].any()
+    d.close()
+
+
+def test_frames_accumulate_and_reset():
+    Wd, Hd = 96, 54
+    sa, cam, o, d = _pair(scenes.cube_scene, Wd, Hd, DEFAULT)
+    d.seed_default()
+    d.render(cam, 1)
+    a1 = d.read_accum()
+    d.render(cam, 2)
+    a3 = d.read_accum()
+    ref, *_ = o.render(cam, 3)
+    assert_bits(a3, ref, "1+2 frames == 3 frames")
+    assert not bits_equal(a1, a3)
+    d.reset()
+    assert not d.read_accum().any()
+    d.close()
+
+
+def test_render_bvh_heat_map():
+    Wd, Hd = 96, 54
+    sa, cam, o, d = _pair(lambda: scenes.bunny_class(24), Wd, Hd, DEFAULT)
+    seeds = seed_stream(0, Wd * Hd)
+    rays = o.generate(cam, 0, Wd * Hd, seeds)
+    steps, _ = o.extend(rays, want_steps=True)
+    d.seed_default()
+    d.render(cam, 1, renderBVH=1)
+    got = d.read_accum().reshape(-1, 4)
+    exp = (steps.astype(np.uint32).astype(np.float32) / np.float32(255.0))
+    assert_bits(got[:, 0], exp, "steps/255 heat map")
+    d.close()
+
+
+def test_edge_cases_empty_and_tiny():
+    # 1x1 frame, 64x1 band (exactly one wave), ragged sizes that are no multiple of the wave or block width
+    for (Wd, Hd) in ((1, 1), (64, 1), (65, 3), (257, 2)):
+        sa, cam, o, d = _pair(scenes.cube_scene, Wd, Hd, DEFAULT)
+        acc, seeds, e, c = o.render(cam, 2)
+        d.seed_default()
+        d.render(cam, 2)
+        assert_bits(d.read_accum(), acc, f"{Wd}x{Hd}")
+        d.close()
+    # a camera that sees nothing: every ray misses, queues run empty after bounce 0
+    s, view = scenes.cube_scene()
+    sa = s.arrays()
+    cam = scenes.make_camera(64, 36, (0, 50, 0), (0, -1, 0.001), fov=40.0)
+    o = Oracle(sa, 64, 36, **DEFAULT)
+    d = Device(64, 36, **DEFAULT)
+    d.upload(sa)
+    acc, *_ = o.render(cam, 1)
+    d.seed_default()
+    d.render(cam, 1)
+    assert_bits(d.read_accum(), acc, "all-miss frame")
+    assert d.counters()["extend_rays"] == 64 * 36
+    d.close()
+
+
+def test_api_error_paths():
+    d = Device(64, 36)
+    with pytest.raises(RtError, match="no scene"):
+        d.render(scenes.make_camera(64, 36, (0, 0, 0), (0, 0, 1)), 1)
+    with pytest.raises(RtError, match="expected"):
+        d.set_seeds(np.zeros(5, np.uint32))
+    s, view = scenes.cube_scene()
+    sa = s.arrays()
+    bad = sa.primIdx.copy()
+    bad[0] = 10 ** 6
+    import copy
+    sb = copy.copy(sa)
+    sb.primIdx = bad
+    with pytest.raises(RtError, match="primIdx"):
+        d.upload(sb)
+    with pytest.raises(RtError):
+        Device(64, 36, y0=30, y1=20)
+    d.close()
+
+
+def test_renderer_mirror_init_tick():
+    """The C++ Renderer mirror (Init / Tick / FocusCamera / ComputeEnergy) drives the same device path."""
+    Wd, Hd = 96, 54
+    s, view = scenes.cube_scene()
+    r = Renderer(s, Wd, Hd)
+    r.SetCamera(view["origin"], view["forward"], fov=view["fov"], aperture=view["aperture"])
+    r.Init()
+    r.Tick(3)
+    img, energy = r.read()
+    cam = r.camera()
+    sa = s.arrays()
+    o = Oracle(sa, Wd, Hd, **DEFAULT)
+    assert cam["focalLength"] == o.focus(Wd // 2, Hd // 2, cam)
+    ref, *_ = o.render(cam, 3)
+    assert_bits(img, ref, "Renderer::Tick x3")
+    assert energy > 0
+    r.close()
+
+
+def test_full_size_properties_1080p():
+    """BASELINE config 3 size (1920x1080): properties that do not need the CPU oracle at full size."""
+    Wd, Hd = 1920, 1080
+    s, view = scenes.sponza_class(0.5)
+    sa = s.arrays()
+    cam = scenes.camera_for(view, Wd, Hd)
+    d = Device(Wd, Hd, **DEFAULT)
+    d.upload(sa)
+    cam["focalLength"] = d.focus(Wd // 2, Hd // 2, cam)
+    d.seed_default()
+    d.render(cam, 2)
+    a = d.read_accum()
+    s2 = d.get_seeds()
+    c = d.counters()
+    # determinism: a second context reproduces the image and RNG state bit for bit
+    d2 = Device(Wd, Hd, **DEFAULT)
+    d2.upload(sa)
+    d2.seed_default()
+    d2.render(cam, 1)
+    d2.render(cam, 1)
+    assert bits_equal(d2.read_accum(), a) and np.array_equal(d2.get_seeds(), s2)
+    assert c["extend_rays"] >= 2 * Wd * Hd and c["primary_rays"] == 2 * Wd * Hd
+    assert np.isfinite(a).all() and (a[..., :3] >= 0).all() and a[..., :3].mean() > 0.01
+    # an oracle spot check on a 16-row band of the same frame
+    o = Oracle(sa, Wd, Hd, **DEFAULT)
+    ref, *_ = o.render(cam, 1, y0=520, y1=536)
+    d3 = Device(Wd, Hd, y0=520, y1=536, **DEFAULT)
+    d3.upload(sa)
+    d3.seed_default()
+    d3.render(cam, 1)
+    assert_bits(d3.read_accum(), ref, "1080p band vs oracle")
+    for x in (d, d2, d3):
+        x.close()

@@ -1,0 +1,269 @@
+"""First-contact GPU probe (verbose): HIP path vs oracle per stage and per frame, then the
+reference code objects (oracle/_ref) vs oracle.  Diagnostic tool, not a test."""
+import ctypes as C
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from magr_ray_tracer_amd import _lib as W, scenes  # noqa: E402
+from magr_ray_tracer_amd.renderer import Device  # noqa: E402
+from oracle.oracle_py import Oracle, seed_stream, S0, S1  # noqa: E402
+
+
+def cmp(name, a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        print(f"  {name}: SHAPE {a.shape} vs {b.shape}")
+        return False
+    av, bv = a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b
+    bad = (av != bv)
+    if a.dtype == np.float32:
+        bad &= ~((a == 0) & (b == 0))
+    nb = int(bad.sum())
+    if nb:
+        idx = np.argwhere(bad)[:3]
+        with np.errstate(all="ignore"):
+            rel = np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b.astype(np.float64)), 1e-30) if a.dtype == np.float32 else None
+        print(f"  {name}: {nb}/{a.size} differ; first {idx.tolist()} a={[a[tuple(i)] for i in idx]} b={[b[tuple(i)] for i in idx]}"
+              + (f" maxrel={np.nanmax(np.where(bad, rel, 0)):.3e}" if rel is not None else ""))
+    else:
+        print(f"  {name}: exact ({a.size})")
+    return nb == 0
+
+
+def stage_compare(name, scene_fn, Wd, Hd, variant, bounces=3):
+    print(f"== {name} {Wd}x{Hd} {variant}")
+    s, view = scene_fn()
+    sa = s.arrays()
+    cam = scenes.camera_for(view, Wd, Hd)
+    o = Oracle(sa, Wd, Hd, **variant)
+    d = Device(Wd, Hd, **variant)
+    d.upload(sa)
+    f_o, f_d = o.focus(Wd // 2, Hd // 2, cam), d.focus(Wd // 2, Hd // 2, cam)
+    print("  focus", f_o, f_d, "OK" if f_o == f_d else "DIFF")
+    cam["focalLength"] = f_o
+    n = Wd * Hd
+    seeds_o = seed_stream(0, n)
+    d.set_seeds(seeds_o.copy())
+    acc_o = np.zeros((Hd, Wd, 4), np.float32)
+    d.reset()
+    d.stage_begin_frame()
+    d.stage_generate(cam)
+    rays_o = o.generate(cam, 0, n, seeds_o)
+    rays_d = d.get_rays(0)
+    for f in ("O", "D", "intensity", "pixelIdx", "bounces", "lastSpecular"):
+        cmp("gen." + f, rays_d[f], rays_o[f])
+    cmp("gen.seeds", d.get_seeds(), seeds_o)
+    sh_all = []
+    for b in range(bounces):
+        steps_o, ctr_o = o.extend(rays_o, want_steps=True)
+        d.stage_extend(b)
+        rays_d = d.get_rays(b)
+        ok = True
+        for f in ("t", "primIdx", "u", "v", "I", "N"):
+            m = rays_o["primIdx"] != -1 if f in ("u", "v") else slice(None)
+            ok &= cmp(f"ext{b}." + f, rays_d[f][m], rays_o[f][m])
+        cmp(f"ext{b}.steps", d.get_steps()[:len(rays_o)], steps_o)
+        nxt_o, sh_o = o.shade(rays_o, acc_o.reshape(-1, 4), seeds_o)
+        d.stage_shade(b)
+        nxt_d = d.get_rays(b + 1)
+        print(f"  shade{b}: ext {len(nxt_o)} vs {len(nxt_d)}; shadow {len(sh_o)}")
+        if len(nxt_o) == len(nxt_d):
+            for f in ("O", "D", "intensity", "pixelIdx", "bounces", "inside", "lastSpecular"):
+                cmp(f"shade{b}." + f, nxt_d[f], nxt_o[f])
+        cmp(f"shade{b}.seeds", d.get_seeds(), seeds_o)
+        rec = d.get_shadow(b, b)
+        if len(rec) == len(sh_o) and len(rec):
+            eps = np.float32(1e-4)
+            cmp(f"shadow{b}.o", rec["o"], (sh_o["I"] + sh_o["L"] * eps)[:, :3])
+            cmp(f"shadow{b}.l", rec["l"], sh_o["L"][:, :3])
+            cmp(f"shadow{b}.tmax", rec["tmax"], sh_o["dist"] - np.float32(2) * eps)
+            cmp(f"shadow{b}.pix", rec["pixelIdx"], sh_o["pixelIdx"])
+        else:
+            print(f"  shadow{b}: count {len(rec)} vs {len(sh_o)}")
+        sh_all.append(sh_o)
+        rays_o = nxt_o
+    if variant.get("shading", 1) == 1:
+        o.connect(np.concatenate(sh_all), acc_o.reshape(-1, 4))
+        d.stage_connect(0, bounces - 1)
+    cmp("accum", d.read_accum(), acc_o)
+    c = d.counters()
+    print("  counters", {k: v for k, v in c.items() if v})
+    d.close()
+
+
+def frame_compare(name, scene_fn, Wd, Hd, variant, frames=3, y0=0, y1=None):
+    print(f"== frames {name} {Wd}x{Hd} {variant} rows [{y0},{y1})")
+    s, view = scene_fn()
+    sa = s.arrays()
+    cam = scenes.camera_for(view, Wd, Hd)
+    o = Oracle(sa, Wd, Hd, **variant)
+    cam["focalLength"] = o.focus(Wd // 2, Hd // 2, cam)
+    t = time.time()
+    acc_o, seeds_o, e, c = o.render(cam, frames, y0=y0, y1=y1)
+    t_o = time.time() - t
+    d = Device(Wd, Hd, y0=y0, y1=y1, **variant)
+    d.upload(sa)
+    d.seed_default()
+    t = time.time()
+    d.render(cam, frames)
+    acc_d = d.read_accum()
+    t_d = time.time() - t
+    ok = cmp("accum", acc_d, acc_o)
+    cmp("seeds", d.get_seeds(), seeds_o)
+    cd = d.counters()
+    print("  oracle ctr", e, c)
+    print("  device ctr", {k: v for k, v in cd.items() if v})
+    print(f"  oracle {t_o:.2f}s device {t_d:.3f}s")
+    d.close()
+    return ok
+
+
+def ref_probe():
+    print("== reference code object probe")
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    R = C.CDLL(os.path.join(ref_dir, "libref_runner.so"))
+    R.ref_last_error.restype = C.c_char_p
+    vp = C.c_void_p
+
+    def chk(rc):
+        if rc != 0:
+            raise RuntimeError(R.ref_last_error().decode())
+    chk(R.ref_init(0))
+    mod = vp()
+    chk(R.ref_load(os.path.join(ref_dir, "wf_nee_cosine_bvh2_rr1_ff1.co").encode(), C.byref(mod)))
+
+    def dbuf(arr=None, nbytes=None):
+        p = vp()
+        nb = arr.nbytes if arr is not None else nbytes
+        chk(R.ref_malloc(C.byref(p), C.c_size_t(nb)))
+        if arr is not None and nb:
+            chk(R.ref_h2d(p, arr.ctypes.data_as(vp), C.c_size_t(nb)))
+        return p
+
+    def rd(p, dtype, n):
+        out = np.zeros(n, dtype=dtype)
+        chk(R.ref_d2h(out.ctypes.data_as(vp), p, C.c_size_t(out.nbytes)))
+        return out
+
+    def launch(name, g, l, args):
+        holders = []
+        for a in args:
+            if isinstance(a, np.ndarray):
+                holders.append(a)
+            else:
+                holders.append(C.c_void_p(a.value if isinstance(a, C.c_void_p) else a))
+        arr = (vp * len(args))(*[h.ctypes.data_as(vp) if isinstance(h, np.ndarray) else C.cast(C.pointer(h), vp) for h in holders])
+        chk(R.ref_launch(mod, name.encode(), g, l, arr))
+
+    Wd, Hd, rows = 1280, 720, 48
+    s, view = scenes.mixed_scene(textured=True)
+    view = dict(view, forward=(0.32, 0.75, 0.92))  # pitch down so that the top rows of the frame see the scene
+    sa = s.arrays()
+    cam = scenes.camera_for(view, Wd, Hd)
+    o = Oracle(sa, Wd, Hd, schedule=S0)
+    cam["focalLength"] = o.focus(Wd // 2, 24, cam)
+    n = Wd * rows
+    seeds = seed_stream(0, n)
+    # generate
+    settings = np.zeros((), dtype=W.Settings)
+    settings["antiAliasing"] = 1
+    settings["numLights"] = len(sa.lights)
+    settings["numPrimitives"] = len(sa.prims)
+    d_rays, d_rays2 = dbuf(nbytes=128 * n), dbuf(nbytes=128 * n)
+    d_set = dbuf(np.ascontiguousarray(settings).reshape(1))
+    d_seeds = dbuf(seeds)
+    launch("generate", n, 256, [d_rays, d_set, d_seeds, np.ascontiguousarray(cam).reshape(1)])
+    rays_r = rd(d_rays, W.Ray, n)
+    seeds_r = rd(d_seeds, np.uint32, n)
+    seeds_o = seeds.copy()
+    rays_o = o.generate(cam, 0, n, seeds_o)
+    print(" generate: reference(GPU) vs oracle")
+    for f in ("O", "D", "rD", "intensity", "t", "primIdx", "bounces", "pixelIdx", "lastSpecular"):
+        cmp("  ref.gen." + f, rays_r[f], rays_o[f])
+    cmp("  ref.gen.seeds", seeds_r, seeds_o)
+    # extend on the ORACLE's rays (identical inputs)
+    d_prims, d_mats = dbuf(sa.prims), dbuf(sa.mats)
+    d_tex, d_lights = dbuf(sa.tex if len(sa.tex) else np.zeros(4, np.float32)), dbuf(sa.lights)
+    d_tlas, d_blas, d_nodes, d_idx = dbuf(sa.tlas), dbuf(sa.blas), dbuf(sa.bvh2), dbuf(sa.primIdx)
+    d_accum = dbuf(nbytes=16 * Wd * Hd)
+    chk(R.ref_h2d(d_rays, rays_o.ctypes.data_as(vp), C.c_size_t(rays_o.nbytes)))
+    settings["numOutRays"] = n
+    settings["numInRays"] = 0
+    chk(R.ref_h2d(d_set, np.ascontiguousarray(settings).reshape(1).ctypes.data_as(vp), C.c_size_t(40)))
+    launch("extend", 256, 256, [d_rays, d_prims, d_tlas, d_blas, d_nodes, d_idx, d_accum, d_set])
+    rays_r = rd(d_rays, W.Ray, n)
+    o.extend(rays_o)
+    print(" extend: reference(GPU) vs oracle on identical rays")
+    for f in ("t", "primIdx", "u", "v", "I", "N"):
+        m = rays_o["primIdx"] != -1 if f in ("u", "v") else slice(None)
+        cmp("  ref.ext." + f, rays_r[f][m], rays_o[f][m])
+    # shade S0: one work-item
+    settings_r = rd(d_set, W.Settings, 1)[0]
+    print("  settings after extend:", settings_r)
+    settings["numOutRays"] = n
+    settings["numInRays"] = 0
+    settings["shadowRays"] = 0
+    chk(R.ref_h2d(d_set, np.ascontiguousarray(settings).reshape(1).ctypes.data_as(vp), C.c_size_t(40)))
+    chk(R.ref_h2d(d_rays, rays_o.ctypes.data_as(vp), C.c_size_t(rays_o.nbytes)))
+    d_shadow = dbuf(nbytes=96 * n)
+    t = time.time()
+    launch("shade", 1, 1, [d_rays, d_rays2, d_shadow, d_prims, d_tex, d_mats, d_lights, d_set, d_accum, d_seeds])
+    print(f"  ref shade S0 took {time.time() - t:.2f}s for {n} rays")
+    st = rd(d_set, W.Settings, 1)[0]
+    nOut, nSh = int(st["numOutRays"]), int(st["shadowRays"])
+    ext_r = rd(d_rays2, W.Ray, n)[:nOut]
+    sh_r = rd(d_shadow, W.ShadowRay, n)[:nSh]
+    acc_r = rd(d_accum, np.float32, 4 * Wd * Hd).reshape(Hd, Wd, 4)
+    seeds_r = rd(d_seeds, np.uint32, n)
+    acc_o = np.zeros((Hd, Wd, 4), np.float32)
+    ext_o, sh_o = o.shade(rays_o, acc_o.reshape(-1, 4), seeds_o)
+    print(f" shade S0: ext {nOut} vs {len(ext_o)}, shadow {nSh} vs {len(sh_o)}; seed0 {seeds_r[0]} vs {seeds_o[0]}")
+    if nOut == len(ext_o):
+        for f in ("O", "D", "intensity", "pixelIdx", "bounces", "inside", "lastSpecular"):
+            cmp("  ref.shade." + f, ext_r[f], ext_o[f])
+    if nSh == len(sh_o):
+        for f in ("I", "L", "Nl", "intensity", "BRDF", "lightIdx", "pixelIdx", "dotNL", "dist"):
+            cmp("  ref.shadow." + f, sh_r[f], sh_o[f])
+    cmp("  ref.shade.accum", acc_r, acc_o)
+    # connect S0
+    if nSh == len(sh_o) and nSh:
+        chk(R.ref_h2d(d_shadow, sh_o.ctypes.data_as(vp), C.c_size_t(sh_o.nbytes)))
+        settings["shadowRays"] = nSh
+        chk(R.ref_h2d(d_set, np.ascontiguousarray(settings).reshape(1).ctypes.data_as(vp), C.c_size_t(40)))
+        zero = np.zeros((Hd, Wd, 4), np.float32)
+        chk(R.ref_h2d(d_accum, zero.ctypes.data_as(vp), C.c_size_t(zero.nbytes)))
+        launch("connect", 1, 1, [d_shadow, d_tlas, d_blas, d_nodes, d_idx, d_prims, d_mats, d_set, d_accum])
+        acc_r = rd(d_accum, np.float32, 4 * Wd * Hd).reshape(Hd, Wd, 4)
+        acc_o = np.zeros((Hd, Wd, 4), np.float32)
+        o.connect(sh_o, acc_o.reshape(-1, 4))
+        cmp("  ref.connect.accum", acc_r, acc_o)
+
+
+if __name__ == "__main__":
+    V = dict(shading=1, sampling=1, accel=0, russian_roulette=True, filter_fireflies=True)
+    tests = [
+        lambda: stage_compare("cube", scenes.cube_scene, 64, 36, V),
+        lambda: stage_compare("mixed", scenes.mixed_scene, 96, 54, V),
+        lambda: frame_compare("cube", scenes.cube_scene, 128, 72, V, frames=4),
+        lambda: frame_compare("mixed-notex", lambda: scenes.mixed_scene(textured=False), 128, 72, V, frames=4),
+        lambda: frame_compare("bunny48", lambda: scenes.bunny_class(48), 160, 90, dict(V, shading=0), frames=4),
+        lambda: frame_compare("sponza.25", lambda: scenes.sponza_class(0.25), 160, 90, V, frames=4),
+        lambda: frame_compare("sponza.25-bvh4", lambda: scenes.sponza_class(0.25), 160, 90, dict(V, accel=1), frames=2),
+        lambda: frame_compare("two_blas", scenes.two_blas_scene, 128, 72, V, frames=2),
+        lambda: frame_compare("sponza.25-band", lambda: scenes.sponza_class(0.25), 160, 90, V, frames=2, y0=30, y1=60),
+        ref_probe,
+    ]
+    sel = [int(a) for a in sys.argv[1:]] or range(len(tests))
+    for i in sel:
+        t = tests[i]
+        try:
+            t()
+        except Exception:
+            traceback.print_exc()
+        sys.stdout.flush()
