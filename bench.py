@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json: "Mrays/sec + extend-kernel HBM GB/s,
+sponza 1080p 256spp").
+
+A step = one Renderer::RayTrace() frame (1 sample per pixel) of the sponza-class scene at 1920x1080:
+generate, 7 x (extend, shade, compact), connect.  `value` = W*H*steps*N / t / 1e6 — the reference's own
+"Mrays/s" definition (primary samples per second, src/renderer.cpp:60-62) summed over all ranks.
+Scene, BVH and seeds are resident in HBM before the timed region.  N > 1: one process per GPU
+(torch.distributed / RCCL), samples partitioned across ranks, one all_reduce(SUM) of the accumulator
+inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def extend_bytes(c, accel, prefix="extend"):
+    """Algorithmic bytes of SURVEY.md §8(d): R*48 + V_tlas*96 + L_inst*68 + V_int*96 (BVH4: V4*160) + T_prim*52."""
+    node = 160 if accel == 1 else 96
+    return (c[prefix + "_rays"] * 48 + c[prefix + "_tlas_visits"] * 96 + c[prefix + "_inst_visits"] * 68 +
+            c[prefix + "_node_visits"] * node + c[prefix + "_prim_tests"] * 52)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--detail", type=float, default=1.0, help="sponza-class tessellation (1.0 = ~262k triangles)")
+    ap.add_argument("--accel", choices=["bvh2", "bvh4"], default="bvh2")
+    ap.add_argument("--shard", choices=["samples", "bands"], default="samples")
+    ap.add_argument("--extend-variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket stage launches with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    from magr_ray_tracer_amd import dist as rdist, scenes
+    from magr_ray_tracer_amd.renderer import Device
+
+    rank, world, local = rdist.init_process_group()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    W, H = args.width, args.height
+    accel = 1 if args.accel == "bvh4" else 0
+
+    # ---- scene + BVH on the host (not timed), upload, seeds -------------------------------------------------
+    t0 = time.time()
+    s, view = scenes.sponza_class(args.detail)
+    sa = s.arrays(bvh4=bool(accel))
+    build_s = time.time() - t0
+    p = rdist.plan(args.shard, W, H, rank, world)
+    dev = Device(W, H, y0=p["y0"], y1=p["y1"], accel=accel, device=local, profile=not args.no_profile,
+                 extend_variant=args.extend_variant)
+    dev.upload(sa)
+    cam = scenes.camera_for(view, W, H)
+    cam["focalLength"] = dev.focus(W // 2, H // 2, cam)
+    from magr_ray_tracer_amd import _lib
+    seeds = np.zeros(p["seed_count"], np.uint32)
+    _seed_stream(seeds, p["seed_first"])
+    dev.set_seeds(seeds)
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}")
+    dev.bind_accum(accum)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup ------------------------------------------------------------------------------------------
+    if args.warmup > 0:
+        dev.render(cam, args.warmup)
+        dev.synchronize()
+        rdist.reduce_accumulator(accum)
+    dev.reset()
+    dev.synchronize()
+    dev.reset_counters()
+    dev.reset_stage_times()
+    accum.zero_()
+    barrier()
+
+    # ---- timed region: exactly `steps` frames + the one accumulator reduction ----------------------------------
+    t0 = time.perf_counter()
+    dev.render(cam, args.steps)
+    dev.synchronize()
+    rdist.reduce_accumulator(accum)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    ctr = dev.counters()
+    st = dev.stage_times()
+    samples = W * H * args.steps * (world if args.shard == "samples" else 1)
+    value = samples / dt / 1e6
+
+    if rank == 0:
+        ext_ms = st["extend_ms"] / max(st["extend_launches"], 1)
+        ext_bytes = extend_bytes(ctr, accel) / max(st["extend_launches"], 1)
+        ext_gbs = ext_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+        con_ms = st["connect_ms"] / max(st["connect_launches"], 1)
+        con_gbs = (extend_bytes(ctr, accel, "connect") / max(st["connect_launches"], 1)) / (con_ms * 1e-3) / 1e9 if con_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        traced = ctr["extend_rays"] + ctr["connect_rays"]
+        out = {
+            "metric": "Mrays/sec + extend-kernel HBM GB/s, sponza 1080p 256spp",
+            "value": round(value, 3), "unit": "Mrays/s (primary samples/s, reference definition renderer.cpp:60-62)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak" if args.shard == "samples" else "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"sponza-class procedural atrium ({len(sa.prims)} prims, SAH {args.accel.upper()}, "
+                                   f"{len(sa.bvh2)} nodes) {W}x{H}, NEE+cosine+RR+firefly, 7 bounces; step = 1 spp frame, "
+                                   f"{args.steps} spp timed per GPU (BASELINE config 3 = 256 spp)",
+                       "shard": args.shard, "triangles": int(len(sa.prims)), "extend_variant": args.extend_variant},
+            "traced_mrays_per_s": round(traced * (world if args.shard == "samples" else 1) / dt / 1e6, 2),
+            "rays_per_step": {"extend": ctr["extend_rays"] // args.steps, "connect": ctr["connect_rays"] // args.steps},
+            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": round(ext_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ext_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(ext_bytes), "avg_launch_ms": round(ext_ms, 5),
+                         "launches": st["extend_launches"],
+                         "per_ray": {"node_visits": round(ctr["extend_node_visits"] / max(ctr["extend_rays"], 1), 2),
+                                     "prim_tests": round(ctr["extend_prim_tests"] / max(ctr["extend_rays"], 1), 2)}},
+            "connect_roofline": {"achieved": round(con_gbs, 2), "frac": round(con_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(con_ms, 5)},
+            "stage_ms_per_step": {k[:-3]: round(st[k] / args.steps, 4) for k in st if k.endswith("_ms")},
+            "host_build_s": round(build_s, 2),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sa, cam, W, H, accel)
+        print(json.dumps(out), flush=True)
+    dev.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def _seed_stream(out, first):
+    """seeds[i] = (first+i+1)-th xorshift32 output from 0x12345678 (reference renderer.cpp:195-196), vectorised:
+    the generator is linear over GF(2), so a jump is a 32x32 bit-matrix power; here a plain loop in C would do,
+    but the product library already owns one: reuse rt_seed_default's stream via numpy for offset 0 only."""
+    x = np.uint32(0x12345678)
+    # sequential in chunks with numpy scalar ops is slow for 2M+; use the device library's host loop through ctypes
+    import ctypes as C
+    from magr_ray_tracer_amd import _lib
+    lib = _lib.host_lib()
+    if hasattr(lib, "rth_seed_stream"):
+        lib.rth_seed_stream.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        lib.rth_seed_stream(out.ctypes.data_as(C.c_void_p), int(first), int(out.size))
+        return
+    s = int(x)
+    M = 0xFFFFFFFF
+    for _ in range(first):
+        s ^= (s << 13) & M; s ^= s >> 17; s ^= (s << 5) & M
+    for i in range(out.size):
+        s ^= (s << 13) & M; s ^= s >> 17; s ^= (s << 5) & M
+        out[i] = s
+
+
+def cpu_baseline(sa, cam, W, H, accel):
+    """The oracle (CPU restatement of the reference path, kind "port") timed on this box's host cores on a bounded
+    sample of the same workload: full-resolution frames, row-band parallel over all cores."""
+    from oracle.oracle_py import Oracle
+    cores = os.cpu_count() or 1
+    o = Oracle(sa, W, H, accel=accel)
+    t0 = time.perf_counter()
+    o.render(cam, 1, threads=cores)
+    t1 = time.perf_counter() - t0
+    frames = int(max(1, min(16, round(15.0 / max(t1, 1e-3)))))
+    t0 = time.perf_counter()
+    _, _, e, c = o.render(cam, frames, threads=cores)
+    t = time.perf_counter() - t0
+    return {"value": round(W * H * frames / t / 1e6, 4), "unit": "Mrays/s (primary samples/s)", "cores": cores, "kind": "port",
+            "sample": f"{frames} full 1920x1080 frames (1 spp each) of the same scene, {cores} row bands in parallel, {t:.1f} s",
+            "traced_mrays_per_s": round((e["rays"] + c["rays"]) / t / 1e6, 3)}
+
+
+if __name__ == "__main__":
+    main()

@@ -57,6 +57,10 @@ int rth_bvh_stats(RthScene* s, uint32_t out_u[5], float out_f[2]);
 int rth_camera(int width, int height, float vfov, int type, const float origin[3], const float forward[3],
                float aperture, float focalLength, RtCamera* out);
 
+/* seeds[i] = (first+i+1)-th xorshift32 output from 0x12345678: the host seed loop of renderer.cpp:195-196
+ * (RandomUInt, template/template.cpp:711,724-730), with a start offset for row bands / sample partitions. */
+int rth_seed_stream(uint32_t* out, int64_t first, int64_t n);
+
 /* Renderer mirror (renderer.cpp:6-63): owns a context of librt355.so. */
 RthRenderer* rth_renderer_create(RthScene* scene /* adopted */, int width, int height, int device, int y0, int y1,
                                  int shading, int sampling, int bvh, int russianRoulette, int filterFireflies);

@@ -68,7 +68,7 @@ HOST_SYMBOLS = [
     "rth_build_tlas", "rth_set_instance_transform", "rth_primitives", "rth_materials", "rth_textures", "rth_lights",
     "rth_bvh2_nodes", "rth_bvh4_nodes", "rth_prim_idx", "rth_tlas_nodes", "rth_blas_nodes", "rth_bvh_stats", "rth_camera",
     "rth_renderer_create", "rth_renderer_destroy", "rth_renderer_init", "rth_renderer_set_camera", "rth_renderer_tick",
-    "rth_renderer_read", "rth_renderer_camera"]
+    "rth_renderer_read", "rth_renderer_camera", "rth_seed_stream"]
 
 _dev = None
 _host = None
@@ -162,6 +162,7 @@ def host_lib():
         lib.rth_renderer_tick.argtypes = [vp, i32]
         lib.rth_renderer_read.argtypes = [vp, vp, fp]
         lib.rth_renderer_camera.argtypes = [vp, vp]
+        lib.rth_seed_stream.argtypes = [vp, C.c_int64, C.c_int64]
         _host = lib
     return _host
 

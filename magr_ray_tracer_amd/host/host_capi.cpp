@@ -146,3 +146,15 @@ int rth_renderer_read(RthRenderer* r, RtFloat4* out, float* energy)
 int rth_renderer_camera(RthRenderer* r, RtCamera* out) { GUARD(*out = r->r->camera.cam) }
 
 } // extern "C"
+
+// seeds[i] = (first+i+1)-th xorshift32 output from 0x12345678 — the reference's host seed loop
+// (src/renderer.cpp:195-196 over template/template.cpp:711,724-730).
+extern "C" int rth_seed_stream(uint32_t* out, int64_t first, int64_t n)
+{
+    if (!out || first < 0 || n < 0) return -1;
+    uint32_t s = 0x12345678u;
+    auto next = [&s]() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; };
+    for (int64_t i = 0; i < first; i++) next();
+    for (int64_t i = 0; i < n; i++) out[i] = next();
+    return 0;
+}

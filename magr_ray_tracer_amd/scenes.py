@@ -97,7 +97,7 @@ def sponza_class(detail=1.0, alpha=1.0):
     s = Scene()
     _std_materials(s)
     d = float(detail)
-    k = lambda v: max(2, int(round(v * d)))  # noqa: E731
+    k = lambda v: max(2, int(round(v * d * 1.25)))  # noqa: E731
     LX, LZ, H = 18.0, 7.0, 14.0
 
     # floor (gently cambered paving) and ribbed long walls, end walls, roof with a central slot

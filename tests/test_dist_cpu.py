@@ -1,0 +1,85 @@
+"""N>1 path on CPU: two processes over gloo exercise the sharding plan and the single accumulator reduction of
+magr_ray_tracer_amd/dist.py.  The per-rank "renderer" here is the oracle (tests may use it); on the GPU box the
+same plan + reduce run with the HIP path (bench.py --gpus N)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from magr_ray_tracer_amd import dist as rdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plan_partitions_rows_and_seeds():
+    W, H = 64, 37
+    for world in (1, 2, 3, 8):
+        rows = []
+        firsts = []
+        for r in range(world):
+            p = rdist.plan("bands", W, H, r, world)
+            rows += list(range(p["y0"], p["y1"]))
+            assert p["seed_first"] == p["y0"] * W and p["seed_count"] == (p["y1"] - p["y0"]) * W
+            q = rdist.plan("samples", W, H, r, world)
+            assert (q["y0"], q["y1"]) == (0, H) and q["seed_count"] == W * H
+            firsts.append(q["seed_first"])
+        assert rows == list(range(H))                       # every row exactly once, in order
+        assert firsts == [r * W * H for r in range(world)]  # disjoint seed slices
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import numpy as np, torch, torch.distributed as dist
+    from magr_ray_tracer_amd import dist as rdist, scenes
+    from oracle.oracle_py import Oracle, seed_stream
+    shard = sys.argv[1]
+    rank, world, local = rdist.init_process_group("gloo")
+    W, H, frames = 48, 28, 2
+    s, view = scenes.cube_scene()
+    sa = s.arrays()
+    cam = scenes.camera_for(view, W, H)
+    p = rdist.plan(shard, W, H, rank, world)
+    o = Oracle(sa, W, H)
+    seeds = seed_stream(p["seed_first"], p["seed_count"])
+    acc, *_ = o.render(cam, frames, seeds=seeds, y0=p["y0"], y1=p["y1"])
+    t = torch.from_numpy(acc)
+    rdist.reduce_accumulator(t)
+    if rank == 0:
+        np.save(sys.argv[2], t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+@pytest.mark.parametrize("shard", ["bands", "samples"])
+def test_two_ranks_gloo_reduce(tmp_path, shard):
+    from magr_ray_tracer_amd import scenes
+    from oracle.oracle_py import Oracle, seed_stream
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % dict(root=ROOT))
+    out = tmp_path / "acc.npy"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", str(script), shard, str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=300, cwd=ROOT)
+    got = np.load(out)
+    W, H, frames = 48, 28, 2
+    s, view = scenes.cube_scene()
+    sa = s.arrays()
+    cam = scenes.camera_for(view, W, H)
+    o = Oracle(sa, W, H)
+    exp = np.zeros((H, W, 4), np.float32)
+    for r in range(2):
+        p = rdist.plan(shard, W, H, r, 2)
+        part, *_ = o.render(cam, frames, seeds=seed_stream(p["seed_first"], p["seed_count"]), y0=p["y0"], y1=p["y1"])
+        exp = exp + part          # two addends: the sum is order-independent, so gloo's reduction must match bit for bit
+    assert np.array_equal(got, exp)
+    if shard == "bands":
+        # zero-padded reduce == gather of the bands
+        p0, p1 = rdist.plan(shard, W, H, 0, 2), rdist.plan(shard, W, H, 1, 2)
+        assert got[p0["y0"]:p0["y1"]].any() and got[p1["y0"]:p1["y1"]].any()
