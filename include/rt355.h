@@ -48,7 +48,9 @@ typedef struct RtConfig {
     int32_t russian_roulette;   /* RUSSIAN_ROULETTE                                           */
     int32_t filter_fireflies;   /* FILTER_FIREFLIES                                           */
     int32_t device;             /* HIP device ordinal                                         */
-    int32_t extend_variant;     /* 0 = default kernel; other values select tuning variants     */
+    int32_t extend_variant;     /* traversal kernels: 0 = best available (derived node/triangle layout + persistent
+                                 * wavefronts when the TLAS has one BLAS), 1 = traverse the reference arrays as uploaded,
+                                 * one ray per lane, 2 = derived layout, one ray per lane                            */
     int32_t profile;            /* 1 = bracket every stage launch with HIP events              */
     int32_t reserved[3];
 } RtConfig;

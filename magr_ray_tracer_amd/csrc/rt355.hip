@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -41,6 +42,11 @@ struct RtCtx {
     std::vector<Ev> evPool; size_t evUsed = 0;
     RtStageTimes times{};
     int maxDepth2 = 0;
+    int layout = 0;   // 0 = traverse the reference arrays as uploaded, 1 = derived pair/triangle-record layout
+    bool persist = false;   // persistent-wavefront traversal (layout 1, single BLAS)
+    bool cursorUsed[2 * (RT_MAX_BOUNCES + 2)] = {};   // work-queue heads consumed since the last k_begin_frame
+    int stackEntries = RT_BVH2_STACK, persistGrid = 0;
+    PersistTune tune{ 64, 20, 6 };
 };
 enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_COMPACT, ST_CONNECT, ST_ACCUM };
 
@@ -59,7 +65,9 @@ template <class T> static int dalloc(std::vector<void*>& bag, T** p, size_t coun
 }
 static void free_bag(std::vector<void*>& bag) { for (void* p : bag) (void)hipFree(p); bag.clear(); }
 
-static size_t stack_bytes(const RtCtx* c) { return (size_t)(c->cfg.accel == RT_ACCEL_BVH4 ? RT_BVH4_STACK : RT_BVH2_STACK) * kBlock * sizeof(uint32_t); }
+// LDS traversal stack: one column per lane; sized at upload to what this scene's trees can need
+// (never more than the reference kernels' 32 / 64 entries).
+static size_t stack_bytes(const RtCtx* c) { return (size_t)c->stackEntries * kBlock * sizeof(uint32_t); }
 
 // ---- profiling brackets --------------------------------------------------------------
 static void ev_begin(RtCtx* c, int stage)
@@ -116,6 +124,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     ctx->nPix = (c.y1 - c.y0) * c.width;
     ctx->firstPixel = c.y0 * c.width;
     ctx->gridMax = (ctx->nPix * std::max(1, c.max_bounces) + kBlock - 1) / kBlock; // connect may cover max_bounces*nPix shadow rays
+    ctx->gridMax = std::max(ctx->gridMax, 4096);                                    // and the persistent grid (<= 256 CUs x 8 blocks)
     ctx->var = DevVariant{ c.shading, c.sampling, c.accel, c.russian_roulette ? 1 : 0, c.filter_fireflies ? 1 : 0, c.max_bounces };
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(RT_E_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
@@ -128,7 +137,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     QA(tO, n); QA(tD, n); QA(tInten, n); QA(tMeta, n); QA(tsA, n); QA(tsB, n); QA(tsC, n);
     QA(sA, nS); QA(sB, nS); QA(sC, nS);
     QA(extMask, nW); QA(shMask, nW); QA(extBase, nW); QA(shBase, nW);
-    QA(nRays, RT_MAX_BOUNCES + 2); QA(nShadow, RT_MAX_BOUNCES + 2);
+    QA(nRays, RT_MAX_BOUNCES + 2); QA(nShadow, RT_MAX_BOUNCES + 2); QA(cursor, 2 * (RT_MAX_BOUNCES + 2));
     QA(seeds, n); QA(accum, (size_t)c.width * c.height); QA(steps, n);
     QA(ctrExtend, (size_t)ctx->gridMax * 5); QA(ctrConnect, (size_t)ctx->gridMax * 5);
 #undef QA
@@ -138,6 +147,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     (void)hipMemsetAsync(q.accum, 0, sizeof(float4) * (size_t)c.width * c.height, ctx->stream);
     (void)hipMemsetAsync(q.nRays, 0, sizeof(int32_t) * (RT_MAX_BOUNCES + 2), ctx->stream);
     (void)hipMemsetAsync(q.nShadow, 0, sizeof(int32_t) * (RT_MAX_BOUNCES + 2), ctx->stream);
+    (void)hipMemsetAsync(q.cursor, 0, sizeof(int32_t) * 2 * (RT_MAX_BOUNCES + 2), ctx->stream);
     (void)hipMemsetAsync(q.ctrExtend, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
     (void)hipMemsetAsync(q.ctrConnect, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
     (void)hipMemsetAsync(q.seeds, 0, sizeof(uint32_t) * n, ctx->stream);
@@ -234,13 +244,16 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         else if ((lr & 0xffffu) >= (uint32_t)nTlas || (lr >> 16) >= (uint32_t)nTlas) return fail(RT_E_INVALID, "tlas node %d: child out of range", i);
     }
     const int stackCap = ctx->cfg.accel == RT_ACCEL_BVH4 ? RT_BVH4_STACK : RT_BVH2_STACK;
+    int stackNeed = 1;
     for (int32_t b = 0; b < nBlas; b++) {
         if (blas[b].bvhIdx >= (uint32_t)nNodes) return fail(RT_E_INVALID, "instance %d: bvhIdx out of range", b);
         int need = ctx->cfg.accel == RT_ACCEL_BVH4 ? bvh4_stack_need((const RtBVHNode4*)bvhNodes, nNodes, blas[b].bvhIdx)
                                                    : bvh2_depth((const RtBVHNode2*)bvhNodes, nNodes, blas[b].bvhIdx);
         if (need < 0) return fail(RT_E_INVALID, "instance %d: malformed BVH (child index out of range or cycle)", b);
         if (need > stackCap) return fail(RT_E_UNSUPPORTED, "instance %d: traversal needs %d stack entries, the reference kernels provide %d", b, need, stackCap);
+        stackNeed = std::max(stackNeed, need);
     }
+    ctx->stackEntries = std::min(stackCap, std::max(stackNeed + 1, 6)); // >= 6: flush_counters reuses 20 words of it
     if (ctx->cfg.accel == RT_ACCEL_BVH2) {
         const RtBVHNode2* n2 = (const RtBVHNode2*)bvhNodes;
         for (int32_t i = 0; i < nNodes; i++) if (n2[i].count > 0 && (uint64_t)n2[i].first + n2[i].count > (uint64_t)nIdx)
@@ -273,8 +286,57 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
     if (rc == RT_OK) rc = upload(ctx, &sc.primIdx, primIdx, (size_t)nIdx);
     if (rc == RT_OK) rc = upload(ctx, &sc.tlas, tlas, (size_t)nTlas);
     if (rc == RT_OK) rc = upload(ctx, &sc.blas, blas, (size_t)nBlas);
+    // Derived layout 1 (rt355_kernels.h, traverse_bvh2_packed): only for BVH2, when the encodings fit.
+    ctx->layout = 0;
+    if (rc == RT_OK && ctx->cfg.accel == RT_ACCEL_BVH2 && ctx->cfg.extend_variant != 1 && nIdx < (1 << 24)) {
+        const RtBVHNode2* n2 = (const RtBVHNode2*)bvhNodes;
+        bool fits = true;
+        for (int32_t i = 0; i < nNodes && fits; i++) if (n2[i].count > 127) fits = false;
+        if (fits) {
+            auto entry = [&](uint32_t i) { return n2[i].count > 0 ? (0x80000000u | (n2[i].count << 24) | n2[i].first) : i; };
+            auto f2u = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+            std::vector<float4> pairs((size_t)nNodes * 4, make_float4(0, 0, 0, 0));
+            for (int32_t i = 0; i < nNodes; i++) {
+                if (n2[i].count > 0) continue;
+                const RtBVHNode2& a = n2[n2[i].first]; const RtBVHNode2& b = n2[n2[i].first + 1];
+                pairs[(size_t)i * 4 + 0] = make_float4(a.aabbMin.x, a.aabbMin.y, a.aabbMin.z, a.aabbMax.x);
+                pairs[(size_t)i * 4 + 1] = make_float4(a.aabbMax.y, a.aabbMax.z, b.aabbMin.x, b.aabbMin.y);
+                pairs[(size_t)i * 4 + 2] = make_float4(b.aabbMin.z, b.aabbMax.x, b.aabbMax.y, b.aabbMax.z);
+                pairs[(size_t)i * 4 + 3] = make_float4(f2u(entry(n2[i].first)), f2u(entry(n2[i].first + 1)), 0, 0);
+            }
+            std::vector<float4> recs((size_t)nIdx * 3);
+            for (int32_t s = 0; s < nIdx; s++) {
+                const RtPrimitive& p = prims[primIdx[s]];
+                const RtTriangle& t = p.obj.triangle;
+                const bool plain = p.objType == RT_PRIM_TRIANGLE && t.v0.w == 0.0f && t.v1.w == 0.0f && t.v2.w == 0.0f;
+                recs[(size_t)s * 3 + 0] = make_float4(t.v0.x, t.v0.y, t.v0.z, t.v1.x);
+                recs[(size_t)s * 3 + 1] = make_float4(t.v1.y, t.v1.z, t.v2.x, t.v2.y);
+                recs[(size_t)s * 3 + 2] = make_float4(t.v2.z, f2u(primIdx[s]), f2u(plain ? 0u : 1u), 0);
+            }
+            std::vector<uint32_t> roots((size_t)nBlas);
+            for (int32_t b = 0; b < nBlas; b++) roots[b] = entry(blas[b].bvhIdx);
+            rc = upload(ctx, &sc.pairs, pairs.data(), pairs.size());
+            if (rc == RT_OK) rc = upload(ctx, &sc.triRecs, recs.data(), recs.size());
+            if (rc == RT_OK) rc = upload(ctx, &sc.rootEntry, roots.data(), roots.size());
+            if (rc == RT_OK) ctx->layout = 1;
+        }
+    }
     if (rc != RT_OK) { free_bag(ctx->sceneAllocs); ctx->sceneLoaded = false; return rc; }
     sc.nLights = nLights; sc.nPrims = nPrims; sc.nBlas = nBlas;
+    // persistent-wavefront traversal: layout 1 and a TLAS whose root is a leaf (one BLAS)
+    ctx->persist = ctx->layout == 1 && tlas[0].leftRight == 0 && ctx->cfg.extend_variant != 2;
+    if (ctx->persist) {
+        int perCU = 0; hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, ctx->cfg.device));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_persist<false>, kBlock, stack_bytes(ctx)));
+        ctx->persistGrid = std::min(ctx->gridMax, std::max(1, perCU) * prop.multiProcessorCount);
+        if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner[,blocksPerCU]" (tuning aid)
+            int a = 0, b = 0, c = 0, d = 0;
+            int k = sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &d);
+            if (k >= 3 && a > 0 && b > 0 && b <= 64 && c > 0) ctx->tune = PersistTune{ a, b, c };
+            if (k == 4 && d > 0) ctx->persistGrid = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount);
+        }
+    }
     ctx->sc = sc;
     ctx->sceneLoaded = true;
     return RT_OK;
@@ -349,6 +411,7 @@ extern "C" int rt_stage_begin_frame(RtCtx* ctx)
     if (!ctx) return fail(RT_E_INVALID, "rt_stage_begin_frame: null context");
     hipLaunchKernelGGL(k_begin_frame, dim3(1), dim3(64), 0, ctx->stream, ctx->q);
     HIPCHK(hipGetLastError());
+    memset(ctx->cursorUsed, 0, sizeof ctx->cursorUsed);
     return RT_OK;
 }
 extern "C" int rt_stage_generate(RtCtx* ctx, const RtCamera* cam, const RtSettings* s)
@@ -365,11 +428,19 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
 {
     int rc = need_scene(ctx, "rt_stage_extend"); if (rc) return rc;
     if (bounce < 0 || bounce >= RT_MAX_BOUNCES + 1) return fail(RT_E_INVALID, "rt_stage_extend: bounce %d", bounce);
+    if (ctx->persist) { // a queue head is good for one launch per frame; re-arm it if this stage is run again
+        if (ctx->cursorUsed[bounce]) HIPCHK(hipMemsetAsync(ctx->q.cursor + bounce, 0, sizeof(int32_t), ctx->stream));
+        ctx->cursorUsed[bounce] = true;
+    }
     ev_begin(ctx, ST_EXTEND);
-    if (ctx->cfg.accel == RT_ACCEL_BVH4)
-        hipLaunchKernelGGL(k_extend<RT_ACCEL_BVH4>, grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
+    if (ctx->persist)
+        hipLaunchKernelGGL((k_trace_persist<false>), dim3(ctx->persistGrid), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+    else if (ctx->cfg.accel == RT_ACCEL_BVH4)
+        hipLaunchKernelGGL((k_extend<RT_ACCEL_BVH4, 0>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
+    else if (ctx->layout == 1)
+        hipLaunchKernelGGL((k_extend<RT_ACCEL_BVH2, 1>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
     else
-        hipLaunchKernelGGL(k_extend<RT_ACCEL_BVH2>, grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
+        hipLaunchKernelGGL((k_extend<RT_ACCEL_BVH2, 0>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
     ev_end(ctx);
     HIPCHK(hipGetLastError());
     return RT_OK;
@@ -396,11 +467,20 @@ extern "C" int rt_stage_connect(RtCtx* ctx, int32_t b0, int32_t b1)
     int rc = need_scene(ctx, "rt_stage_connect"); if (rc) return rc;
     if (b0 < 0 || b1 < b0 || b1 >= RT_MAX_BOUNCES) return fail(RT_E_INVALID, "rt_stage_connect: bounce range [%d,%d]", b0, b1);
     const int cap = ctx->nPix * (b1 - b0 + 1);
+    if (ctx->persist) {
+        const int ci = (RT_MAX_BOUNCES + 2) + b0;
+        if (ctx->cursorUsed[ci]) HIPCHK(hipMemsetAsync(ctx->q.cursor + ci, 0, sizeof(int32_t), ctx->stream));
+        ctx->cursorUsed[ci] = true;
+    }
     ev_begin(ctx, ST_CONNECT);
-    if (ctx->cfg.accel == RT_ACCEL_BVH4)
-        hipLaunchKernelGGL(k_connect<RT_ACCEL_BVH4>, grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
+    if (ctx->persist)
+        hipLaunchKernelGGL((k_trace_persist<true>), dim3(ctx->persistGrid), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1, 0, ctx->tune);
+    else if (ctx->cfg.accel == RT_ACCEL_BVH4)
+        hipLaunchKernelGGL((k_connect<RT_ACCEL_BVH4, 0>), grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
+    else if (ctx->layout == 1)
+        hipLaunchKernelGGL((k_connect<RT_ACCEL_BVH2, 1>), grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
     else
-        hipLaunchKernelGGL(k_connect<RT_ACCEL_BVH2>, grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
+        hipLaunchKernelGGL((k_connect<RT_ACCEL_BVH2, 0>), grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
     ev_end(ctx);
     ev_begin(ctx, ST_ACCUM);
     for (int b = b0; b <= b1; b++)
@@ -449,9 +529,9 @@ extern "C" int rt_focus(RtCtx* ctx, int32_t x, int32_t y, const RtCamera* cam, f
     if (!cam || !t) return fail(RT_E_INVALID, "rt_focus: null argument");
     HIPCHK(hipSetDevice(ctx->cfg.device));
     if (ctx->cfg.accel == RT_ACCEL_BVH4)
-        hipLaunchKernelGGL(k_focus<RT_ACCEL_BVH4>, dim3(1), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, *cam, x, y, ctx->cfg.width, ctx->cfg.height, ctx->dFocus);
+        hipLaunchKernelGGL((k_focus<RT_ACCEL_BVH4>), dim3(1), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, *cam, x, y, ctx->cfg.width, ctx->cfg.height, ctx->dFocus);
     else
-        hipLaunchKernelGGL(k_focus<RT_ACCEL_BVH2>, dim3(1), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, *cam, x, y, ctx->cfg.width, ctx->cfg.height, ctx->dFocus);
+        hipLaunchKernelGGL((k_focus<RT_ACCEL_BVH2>), dim3(1), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, *cam, x, y, ctx->cfg.width, ctx->cfg.height, ctx->dFocus);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(t, ctx->dFocus, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

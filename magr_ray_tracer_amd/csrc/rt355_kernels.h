@@ -46,6 +46,10 @@ struct DevScene {
     const uint32_t*      primIdx;
     const RtTLASNode*    tlas;
     const RtBVHInstance* blas;
+    // derived at upload from the unchanged BVH2 arrays (layout 1, see traverse_bvh2_packed)
+    const float4*        pairs;      // [nNodes][4]  both child boxes + encoded child entries of interior node i
+    const float4*        triRecs;    // [nIdx][3]    leaf-ordered triangle vertices + primitive id
+    const uint32_t*      rootEntry;  // [nBlas]      encoded root of every instance
     int32_t nLights, nPrims, nBlas;
 };
 struct DevQueues {
@@ -60,6 +64,7 @@ struct DevQueues {
     uint32_t* extBase; uint32_t* shBase;
     int32_t* nRays;    // [RT_MAX_BOUNCES+2]  rays entering bounce b
     int32_t* nShadow;  // [RT_MAX_BOUNCES+2]  shadow rays of bounce b occupy [nShadow[b], nShadow[b+1])
+    int32_t* cursor;   // [2*(RT_MAX_BOUNCES+2)] work-queue heads of the persistent kernels (extend: [b], connect: [9+b])
     uint32_t* seeds;   // one RNG stream per band slot
     float4* accum;     // full frame, indexed by global pixel index
     int32_t* steps;    // per-ray steps of the last extend (debug / heat map), may be null
@@ -222,6 +227,79 @@ RT_FORCEINLINE int traverse_bvh2(const DevScene& sc, TRay& r, uint32_t root, uin
     return steps;
 }
 
+// ---- layout 1: the same BVH2, re-laid-out at upload for one dependent fetch per step ---------------
+// The reference node array is uploaded unchanged; from it rt_upload_scene derives
+//   pairs[i]   (64 B, one cache-line-aligned fetch) for every interior node i:
+//              q0 = (c1.min.xyz, c1.max.x) q1 = (c1.max.yz, c2.min.xy) q2 = (c2.min.z, c2.max.xyz)
+//              q3 = (entry(c1), entry(c2), -, -) with c1 = nodes[i].first, c2 = c1 + 1
+//   entry(n)   = n                                   interior node id
+//              = 0x80000000 | count << 24 | first    leaf (count <= 127, first < 2^24)
+//   triRecs[s] (48 B) for every primIdx slot s: the three vertices (xyz) and the primitive id, in leaf
+//              order, so a leaf's triangles are contiguous and the primIdx indirection disappears.
+// Visit order, slab arithmetic, tie rules and `steps` are those of traverse_bvh2 (bvh.cl:13-54): results
+// are bit-identical; what changes is that a step costs one dependent fetch instead of two (node header,
+// then child boxes) and a triangle test one instead of two (index, then 128-byte Primitive).
+static constexpr uint32_t kLeafBit = 0x80000000u;
+RT_FORCEINLINE void test_tri_packed(const DevScene& sc, uint32_t slot, TRay& r)
+{
+    const float4* rec = sc.triRecs + (size_t)slot * 3;
+    const float4 a = rec[0], b = rec[1], c = rec[2];
+    const int idx = __float_as_int(c.y);
+    if (__float_as_int(c.z) != 0) { test_prim(sc, idx, r); return; } // not a plain triangle: reference-layout test
+    const float4 O = mk4(r.ox, r.oy, r.oz, 0.0f), D = mk4(r.dx, r.dy, r.dz, 0.0f);
+    const float4 v0 = mk4(a.x, a.y, a.z, 0.0f), v1 = mk4(a.w, b.x, b.y, 0.0f), v2 = mk4(b.z, b.w, c.x, 0.0f);
+    float4 v0v1 = sub4(v1, v0), v0v2 = sub4(v2, v0);
+    float4 pvec = cross4(D, v0v2);
+    float det = dot4(v0v1, pvec);
+    if (fabsf(det) < 1e-8f) return;
+    float invDet = 1.0f / det;
+    float4 tvec = sub4(O, v0);
+    float u = dot4(tvec, pvec) * invDet;
+    if (u < 0 || u > 1) return;
+    float4 qvec = cross4(tvec, v0v1);
+    float v = dot4(D, qvec) * invDet;
+    if (v < 0 || u + v > 1) return;
+    float t = dot4(v0v2, qvec) * invDet;
+    if (t > r.t || t < 0) return;
+    r.t = t; r.prim = idx; r.u = u; r.v = v;
+}
+template <bool OCC>
+RT_FORCEINLINE int traverse_bvh2_packed(const DevScene& sc, TRay& r, uint32_t rootEntry, uint32_t* stk, WorkCtr& wc)
+{
+    uint32_t cur = rootEntry, sp = 0;
+    int steps = 0;
+    const float tLight = r.t;
+    for (;;) {
+        if (cur & kLeafBit) {
+            const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
+            for (uint32_t i = 0; i < count; i++) {
+                wc.prim++;
+                test_tri_packed(sc, first + i, r);
+                if (OCC && r.t < tLight) return -1;
+            }
+            if (sp == 0) break;
+            cur = STK(--sp);
+            continue;
+        }
+        wc.node++;
+        const float4* p = sc.pairs + (size_t)cur * 4;
+        const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        float d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
+        float d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
+        uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
+        if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t e = e1; e1 = e2; e2 = e; }
+        if (d1 >= tLight) {
+            if (sp == 0) break;
+            cur = STK(--sp);
+        } else {
+            steps++;
+            cur = e1;
+            if (d2 < tLight) { STK(sp) = e2; sp++; steps++; }
+        }
+    }
+    return steps;
+}
+
 // BVH4 traversal, bvh.cl:55-96 (children visited in slot order, all four distances taken
 // at node entry).
 template <bool OCC>
@@ -264,8 +342,8 @@ RT_FORCEINLINE int traverse_bvh4(const DevScene& sc, TRay& r, uint32_t root, uin
 }
 
 // instanceIntersect, tlas.cl:9-26 with transformRay :3-8 and util.cl:61-87.
-template <int ACCEL, bool OCC>
-RT_FORCEINLINE int traverse_instance(const DevScene& sc, TRay& r, const RtBVHInstance* inst, uint32_t* stk, WorkCtr& wc)
+template <int ACCEL, int LAYOUT, bool OCC>
+RT_FORCEINLINE int traverse_instance(const DevScene& sc, TRay& r, const RtBVHInstance* inst, uint32_t instIdx, uint32_t* stk, WorkCtr& wc)
 {
     const float* T = inst->invT;
     const float bx = r.ox, by = r.oy, bz = r.oz, bdx = r.dx, bdy = r.dy, bdz = r.dz, brx = r.rx, bry = r.ry, brz = r.rz;
@@ -275,15 +353,17 @@ RT_FORCEINLINE int traverse_instance(const DevScene& sc, TRay& r, const RtBVHIns
     r.oz = dot3(mk4(T[8], T[9], T[10], 0), Ov) + T[11];
     r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
     wc.inst++;
-    int steps = ACCEL == RT_ACCEL_BVH4 ? traverse_bvh4<OCC>(sc, r, inst->bvhIdx, stk, wc)
-                                       : traverse_bvh2<OCC>(sc, r, inst->bvhIdx, stk, wc);
+    int steps;
+    if (ACCEL == RT_ACCEL_BVH4) steps = traverse_bvh4<OCC>(sc, r, inst->bvhIdx, stk, wc);
+    else if (LAYOUT == 1) steps = traverse_bvh2_packed<OCC>(sc, r, sc.rootEntry[instIdx], stk, wc);
+    else steps = traverse_bvh2<OCC>(sc, r, inst->bvhIdx, stk, wc);
     r.ox = bx; r.oy = by; r.oz = bz; r.dx = bdx; r.dy = bdy; r.dz = bdz; r.rx = brx; r.ry = bry; r.rz = brz;
     return steps;
 }
 
 // intersectTLAS, tlas.cl:28-77.  The TLAS stack (<= 32 entries of 16-bit ids) is a
 // private array; with a single BLAS the root is a leaf and it is never touched.
-template <int ACCEL, bool OCC>
+template <int ACCEL, int LAYOUT, bool OCC>
 RT_FORCEINLINE int traverse_tlas(const DevScene& sc, TRay& r, uint32_t* stk, WorkCtr& wc)
 {
     const RtTLASNode* tl = sc.tlas;
@@ -294,7 +374,7 @@ RT_FORCEINLINE int traverse_tlas(const DevScene& sc, TRay& r, uint32_t* stk, Wor
     for (;;) {
         const uint2 lr = *reinterpret_cast<const uint2*>(&tl[node].leftRight);
         if (lr.x == 0) {
-            int value = traverse_instance<ACCEL, OCC>(sc, r, sc.blas + lr.y, stk, wc);
+            int value = traverse_instance<ACCEL, LAYOUT, OCC>(sc, r, sc.blas + lr.y, lr.y, stk, wc);
             if (OCC && value == -1) return -1;
             steps += value;
             if (sp == 0) break;
@@ -346,6 +426,7 @@ __global__ void k_reset(float4* accum, int32_t first, int32_t n)
 __global__ void k_begin_frame(DevQueues q) // renderer.cpp:66-69
 {
     if (threadIdx.x == 0) { q.nRays[0] = q.nPix; q.nShadow[0] = 0; }
+    if (threadIdx.x < 2 * (RT_MAX_BOUNCES + 2)) q.cursor[threadIdx.x] = 0;
 }
 
 // ------------------------------------------------------------------ k_generate
@@ -388,7 +469,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevQueues q, RtCamera cam, 
 }
 
 // ------------------------------------------------------------------ k_extend (variant 0: one ray per lane)
-template <int ACCEL>
+template <int ACCEL, int LAYOUT>
 __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int bounce, int renderBVH)
 {
     extern __shared__ uint32_t stk[];
@@ -402,13 +483,129 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int
         r.ox = O.x; r.oy = O.y; r.oz = O.z; r.dx = D.x; r.dy = D.y; r.dz = D.z;
         r.rx = 1.0f / D.x; r.ry = 1.0f / D.y; r.rz = 1.0f / D.z;
         r.t = kFar; r.prim = -1; r.u = 0.0f; r.v = 0.0f;
-        int steps = traverse_tlas<ACCEL, false>(sc, r, stk, wc);
+        int steps = traverse_tlas<ACCEL, LAYOUT, false>(sc, r, stk, wc);
         rays = 1;
         q.hit[i] = mk4(r.t, __int_as_float(r.prim), r.u, r.v);
         if (q.steps) q.steps[i] = steps;
         if (renderBVH) q.accum[q.firstPixel + i] = splat((float)(uint32_t)steps / 255.f); // wavefront.cl:67
     }
     flush_counters(q.ctrExtend, rays, wc, stk);
+}
+
+// ------------------------------------------------------------------ k_trace_persist (layout 1, single BLAS)
+// Persistent wavefronts (north star; Aila & Laine style): a fixed grid of resident waves pulls rays from
+// the bounce's queue.  A wave dequeues a chunk of rays with ONE atomic (lane 0, broadcast), hands them to
+// its idle lanes by ballot + prefix count, and keeps traversing; whenever at least kRefill lanes have
+// finished their ray it tops the idle lanes up again, so SIMD lanes stay busy although traversal lengths
+// differ by an order of magnitude between rays.  Each lane advances its own ray by one event per
+// iteration (one interior visit, or one triangle test) with the exact per-ray visit order of
+// traverse_bvh2_packed, so hits, `steps` and the work counters are bit-identical to the one-ray-per-lane
+// kernels; only the lane<->ray assignment differs.  Every wave reaches the exit condition (queue empty and
+// all its lanes idle), so the grid always drains.
+// Work distribution: the first chunk of every wave is static (chunk id = global wave id, no atomic, so the
+// launch does not start with thousands of waves hammering one counter); further chunks are dequeued.
+struct PersistTune { int chunk, refill, inner; };   // rays per dequeue, idle lanes that trigger a top-up, events between checks
+
+template <bool OCC>
+__global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues q, int b0, int b1, int renderBVH, PersistTune tune)
+{
+    const int kChunk = tune.chunk, kRefill = tune.refill, kInner = tune.inner;
+    extern __shared__ uint32_t stk[];
+    const int lane = threadIdx.x & 63;
+    // queue window: extend -> rays [0, nRays[b0]); connect -> shadow rays [nShadow[b0], nShadow[b1+1])
+    const int qFirst = OCC ? q.nShadow[b0] : 0;
+    const int n = OCC ? q.nShadow[b1 + 1] - qFirst : q.nRays[b0];
+    int32_t* cursor = q.cursor + (OCC ? (RT_MAX_BOUNCES + 2) + b0 : b0);
+    const RtBVHInstance* inst = sc.blas + sc.tlas[0].BLASidx;
+    const uint32_t rootEntry = sc.rootEntry[sc.tlas[0].BLASidx];
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = inst->invT[k];
+
+    WorkCtr wc = { 0, 0, 0, 0 };
+    uint32_t rays = 0;
+    TRay r; r.t = 0; r.prim = -1; r.u = r.v = 0; r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.rx = r.ry = r.rz = 0;
+    uint32_t cur = 0, sp = 0;
+    int slot = -1, steps = 0;
+    float tLight = 0;
+    const int nWaves = gridDim.x * (kBlock / 64), waveId = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    int chunkNext = min(waveId * kChunk, n), chunkEnd = min(waveId * kChunk + kChunk, n);   // wave-uniform
+    bool exhausted = false;                                                                  // wave-uniform
+
+    for (;;) {
+        const unsigned long long idleMask = __ballot(slot < 0);
+        const int nIdle = __popcll(idleMask);
+        if (nIdle == 64 && exhausted && chunkNext >= chunkEnd) break;
+        if (nIdle >= kRefill && !(exhausted && chunkNext >= chunkEnd)) {
+            if (chunkNext >= chunkEnd) {           // dequeue a chunk for this wave
+                int c = 0;
+                if (lane == 0) c = atomicAdd(cursor, kChunk);
+                c = __shfl(c, 0, 64) + nWaves * kChunk;
+                chunkNext = c; chunkEnd = min(c + kChunk, n);
+                if (c >= n) { exhausted = true; chunkNext = chunkEnd = 0; }
+            }
+            if (chunkNext < chunkEnd) {
+                const int rank = __popcll(idleMask & ((1ull << lane) - 1ull));
+                const int idx = chunkNext + rank;
+                if (slot < 0 && idx < chunkEnd) {
+                    float4 O, D; float tmax;
+                    if (OCC) { const float4 a = q.sA[qFirst + idx], b = q.sB[qFirst + idx]; O = a; D = b; tmax = a.w; }
+                    else { O = q.O[idx]; D = q.D[idx]; tmax = kFar; }
+                    // transformRay (tlas.cl:3-8) of the single instance, same arithmetic as traverse_instance
+                    const float4 Dv = mk4(D.x, D.y, D.z, 0.0f), Ov = mk4(O.x, O.y, O.z, 0.0f);
+                    r.dx = dot3(mk4(T[0], T[1], T[2], 0), Dv); r.dy = dot3(mk4(T[4], T[5], T[6], 0), Dv); r.dz = dot3(mk4(T[8], T[9], T[10], 0), Dv);
+                    r.ox = dot3(mk4(T[0], T[1], T[2], 0), Ov) + T[3]; r.oy = dot3(mk4(T[4], T[5], T[6], 0), Ov) + T[7];
+                    r.oz = dot3(mk4(T[8], T[9], T[10], 0), Ov) + T[11];
+                    r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
+                    r.t = tmax; r.prim = -1; r.u = 0.0f; r.v = 0.0f;
+                    tLight = tmax; cur = rootEntry; sp = 0; steps = 0; slot = idx;
+                    rays++; wc.inst++;
+                }
+                chunkNext = min(chunkNext + nIdle, chunkEnd);
+            }
+        }
+#pragma unroll 1
+        for (int it = 0; it < kInner; it++) {
+            if (slot >= 0) {
+                bool done = false, occluded = false;
+                if (cur & kLeafBit) {
+                    const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
+                    wc.prim++;
+                    test_tri_packed(sc, first, r);
+                    if (OCC && r.t < tLight) { done = true; occluded = true; }
+                    else if (count > 1) cur = kLeafBit | ((count - 1) << 24) | (first + 1);
+                    else if (sp == 0) done = true;
+                    else cur = STK(--sp);
+                } else {
+                    wc.node++;
+                    const float4* p = sc.pairs + (size_t)cur * 4;
+                    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                    float d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
+                    float d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
+                    uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
+                    if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t e = e1; e1 = e2; e2 = e; }
+                    if (d1 >= tLight) {
+                        if (sp == 0) done = true;
+                        else cur = STK(--sp);
+                    } else {
+                        steps++;
+                        cur = e1;
+                        if (d2 < tLight) { STK(sp) = e2; sp++; steps++; }
+                    }
+                }
+                if (done) {
+                    if (OCC) { if (occluded) q.sC[qFirst + slot] = splat(0.0f); }
+                    else {
+                        q.hit[slot] = mk4(r.t, __int_as_float(r.prim), r.u, r.v);
+                        if (q.steps) q.steps[slot] = steps;
+                        if (renderBVH) q.accum[q.firstPixel + slot] = splat((float)(uint32_t)steps / 255.f);
+                    }
+                    slot = -1;
+                }
+            }
+        }
+    }
+    flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
 }
 
 // ------------------------------------------------------------------ shading helpers
@@ -686,7 +883,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(DevQueues q, int bounce)
 }
 
 // ------------------------------------------------------------------ k_connect: any-hit over shadow rays [nShadow[b0], nShadow[b1+1])
-template <int ACCEL>
+template <int ACCEL, int LAYOUT>
 __global__ __launch_bounds__(kBlock) void k_connect(DevScene sc, DevQueues q, int b0, int b1)
 {
     extern __shared__ uint32_t stk[];
@@ -701,7 +898,7 @@ __global__ __launch_bounds__(kBlock) void k_connect(DevScene sc, DevQueues q, in
         r.rx = 1.0f / b.x; r.ry = 1.0f / b.y; r.rz = 1.0f / b.z;
         r.t = a.w; r.prim = -1; r.u = 0.0f; r.v = 0.0f;
         rays = 1;
-        if (traverse_tlas<ACCEL, true>(sc, r, stk, wc) == -1) q.sC[first + i] = splat(0.0f); // occluded: contributes nothing
+        if (traverse_tlas<ACCEL, LAYOUT, true>(sc, r, stk, wc) == -1) q.sC[first + i] = splat(0.0f); // occluded: contributes nothing
     }
     flush_counters(q.ctrConnect, rays, wc, stk);
 }
@@ -735,7 +932,7 @@ __global__ void k_focus(DevScene sc, RtCamera cam, int x, int y, int W, int H, f
     r.rx = 1.0f / D.x; r.ry = 1.0f / D.y; r.rz = 1.0f / D.z;
     r.t = kFar; r.prim = -1; r.u = r.v = 0.0f;
     WorkCtr wc = { 0, 0, 0, 0 };
-    traverse_tlas<ACCEL, false>(sc, r, stk, wc);
+    traverse_tlas<ACCEL, 0, false>(sc, r, stk, wc);
     *out = r.t;
 }
 

@@ -22,7 +22,7 @@ TRI_SCENES = {
 
 def _pair(scene_fn, Wd, Hd, variant, y0=0, y1=None):
     s, sa, cam = build(scene_fn, Wd, Hd)
-    o = Oracle(sa, Wd, Hd, **variant)
+    o = Oracle(sa, Wd, Hd, **{k: v for k, v in variant.items() if k != "extend_variant"})
     d = Device(Wd, Hd, y0=y0, y1=y1, **variant)
     d.upload(sa)
     return sa, cam, o, d
@@ -89,6 +89,8 @@ def test_stage_by_stage_bit_exact(scene):
 
 VARIANTS = [
     dict(),
+    dict(extend_variant=1),      # traverse the reference arrays as uploaded (no derived layout)
+    dict(extend_variant=2),      # derived layout, one ray per lane (no persistent wavefronts)
     dict(shading=0),
     dict(shading=0, sampling=0, russian_roulette=False, filter_fireflies=False),
     dict(sampling=0),

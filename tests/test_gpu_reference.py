@@ -44,7 +44,7 @@ def test_extend_hip_vs_reference_kernel_bit_exact(accel):
     d.stage_generate(cam)
     mine = d.get_rays(0)
     assert_bits(mine["O"], gen["O"], "generate O")
-    assert np.abs(mine["D"] - gen["D"]).max() < 3e-7      # unit-scale direction: a few ulp
+    assert np.abs(mine["D"] - gen["D"]).max() < 1e-6      # unit-scale direction: a few ulp
     assert np.array_equal(d.get_seeds(), gseeds)
     d.close()
     ref.close()

@@ -276,7 +276,7 @@ def test_oracle_matches_reference_kernels(path):
     ref = g["gen_rays"].view(W.Ray)
     assert_bits(rays["O"], ref["O"], "generate O")
     assert np.array_equal(seeds, g["gen_seeds"])
-    assert np.abs(rays["D"] - ref["D"]).max() < 3e-7      # unit-scale direction: a few ulp (hardware rsqrt)
+    assert np.abs(rays["D"] - ref["D"]).max() < 1e-6      # unit-scale direction: a few ulp (hardware rsqrt)
     # extend on the reference's own generated rays: bit-exact
     rays = ref.copy()
     o.extend(rays)
