@@ -45,8 +45,11 @@ struct RtCtx {
     int layout = 0;   // 0 = traverse the reference arrays as uploaded, 1 = derived pair/triangle-record layout
     bool persist = false;   // persistent-wavefront traversal (layout 1, single BLAS)
     bool cursorUsed[2 * (RT_MAX_BOUNCES + 2)] = {};   // work-queue heads consumed since the last k_begin_frame
+    bool shadeRun[RT_MAX_BOUNCES + 1] = {};           // shade(b) launched since the last k_begin_frame
+    bool generated = false;                           // generate launched since the last k_begin_frame
     int stackEntries = RT_BVH2_STACK, persistGrid = 0;
     PersistTune tune{ 64, 20, 6 };
+    int shadeGrid = 1024;   // co-resident workgroups of k_shade (see the kernel's comment); set in rt_create
 };
 enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_COMPACT, ST_CONNECT, ST_ACCUM };
 
@@ -126,17 +129,24 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     ctx->gridMax = (ctx->nPix * std::max(1, c.max_bounces) + kBlock - 1) / kBlock; // connect may cover max_bounces*nPix shadow rays
     ctx->gridMax = std::max(ctx->gridMax, 4096);                                    // and the persistent grid (<= 256 CUs x 8 blocks)
     ctx->var = DevVariant{ c.shading, c.sampling, c.accel, c.russian_roulette ? 1 : 0, c.filter_fireflies ? 1 : 0, c.max_bounces };
+    {   // k_shade's grid must be co-resident: half of what the occupancy query admits, at most 4 per CU
+        hipDeviceProp_t prop; int perCU = 0;
+        HIPCHK(hipGetDeviceProperties(&prop, c.device));
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<true>, kBlock, 0));
+        ctx->shadeGrid = prop.multiProcessorCount * std::max(1, std::min(4, perCU / 2));
+        if (const char* g = getenv("RT355_SHADE_PER_CU")) { int v = atoi(g); if (v > 0 && v <= std::max(1, perCU - 1)) ctx->shadeGrid = prop.multiProcessorCount * v; }
+    }
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail(RT_E_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     DevQueues& q = ctx->q;
-    const size_t n = (size_t)ctx->nPix, nS = n * (size_t)c.max_bounces, nW = (n + 63) / 64;
+    const size_t n = (size_t)ctx->nPix, nS = n * (size_t)c.max_bounces;
     int rc = RT_OK;
     auto& bag = ctx->queueAllocs;
 #define QA(field, count) if (rc == RT_OK) rc = dalloc(bag, &q.field, count)
-    QA(O, n); QA(D, n); QA(inten, n); QA(meta, n); QA(hit, n);
-    QA(tO, n); QA(tD, n); QA(tInten, n); QA(tMeta, n); QA(tsA, n); QA(tsB, n); QA(tsC, n);
+    const size_t nTiles = (n + kBlock - 1) / kBlock;
+    for (int k = 0; k < 2; k++) { QA(O[k], n); QA(D[k], n); QA(inten[k], n); QA(meta[k], n); QA(tile[k], nTiles + 2); }
+    QA(hit, n);
     QA(sA, nS); QA(sB, nS); QA(sC, nS);
-    QA(extMask, nW); QA(shMask, nW); QA(extBase, nW); QA(shBase, nW);
     QA(nRays, RT_MAX_BOUNCES + 2); QA(nShadow, RT_MAX_BOUNCES + 2); QA(cursor, 2 * (RT_MAX_BOUNCES + 2));
     QA(seeds, n); QA(accum, (size_t)c.width * c.height); QA(steps, n);
     QA(ctrExtend, (size_t)ctx->gridMax * 5); QA(ctrConnect, (size_t)ctx->gridMax * 5);
@@ -151,6 +161,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     (void)hipMemsetAsync(q.ctrExtend, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
     (void)hipMemsetAsync(q.ctrConnect, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
     (void)hipMemsetAsync(q.seeds, 0, sizeof(uint32_t) * n, ctx->stream);
+    for (int k = 0; k < 2; k++) (void)hipMemsetAsync(q.tile[k], 0, sizeof(unsigned long long) * (nTiles + 2), ctx->stream);
     (void)hipMemsetAsync(q.hit, 0, sizeof(float4) * n, ctx->stream);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *out = ctx;
@@ -412,6 +423,8 @@ extern "C" int rt_stage_begin_frame(RtCtx* ctx)
     hipLaunchKernelGGL(k_begin_frame, dim3(1), dim3(64), 0, ctx->stream, ctx->q);
     HIPCHK(hipGetLastError());
     memset(ctx->cursorUsed, 0, sizeof ctx->cursorUsed);
+    memset(ctx->shadeRun, 0, sizeof ctx->shadeRun);
+    ctx->generated = false;
     return RT_OK;
 }
 extern "C" int rt_stage_generate(RtCtx* ctx, const RtCamera* cam, const RtSettings* s)
@@ -422,6 +435,7 @@ extern "C" int rt_stage_generate(RtCtx* ctx, const RtCamera* cam, const RtSettin
     ev_end(ctx);
     HIPCHK(hipGetLastError());
     ctx->primaryRays += (uint64_t)ctx->nPix;
+    ctx->generated = true;
     return RT_OK;
 }
 extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
@@ -449,16 +463,20 @@ extern "C" int rt_stage_shade(RtCtx* ctx, int32_t bounce)
 {
     int rc = need_scene(ctx, "rt_stage_shade"); if (rc) return rc;
     if (bounce < 0 || bounce >= RT_MAX_BOUNCES) return fail(RT_E_INVALID, "rt_stage_shade: bounce %d", bounce);
+    // The scan state of bounce b is armed by generate (b = 0) or by shade(b-1); re-arm it by hand when this
+    // stage is run out of sequence (stage-level API used by the tests) or twice for the same bounce.
+    if (ctx->shadeRun[bounce] || (bounce > 0 && !ctx->shadeRun[bounce - 1]) || (bounce == 0 && !ctx->generated)) {
+        const size_t nTiles = ((size_t)ctx->nPix + kBlock - 1) / kBlock;
+        HIPCHK(hipMemsetAsync(ctx->q.tile[bounce & 1], 0, sizeof(unsigned long long) * (nTiles + 2), ctx->stream));
+    }
     ev_begin(ctx, ST_SHADE);
+    const dim3 sg((unsigned)std::max(1, std::min(ctx->shadeGrid, (ctx->nPix + kBlock - 1) / kBlock)));
     if (ctx->cfg.shading == RT_SHADING_NEE)
-        hipLaunchKernelGGL(k_shade<true>, grid_for(ctx->nPix), dim3(kBlock), 0, ctx->stream, ctx->sc, ctx->q, ctx->var, bounce);
+        hipLaunchKernelGGL(k_shade<true>, sg, dim3(kBlock), 0, ctx->stream, ctx->sc, ctx->q, ctx->var, bounce);
     else
-        hipLaunchKernelGGL(k_shade<false>, grid_for(ctx->nPix), dim3(kBlock), 0, ctx->stream, ctx->sc, ctx->q, ctx->var, bounce);
+        hipLaunchKernelGGL(k_shade<false>, sg, dim3(kBlock), 0, ctx->stream, ctx->sc, ctx->q, ctx->var, bounce);
     ev_end(ctx);
-    ev_begin(ctx, ST_COMPACT);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->q, bounce);
-    hipLaunchKernelGGL(k_compact, grid_for(ctx->nPix), dim3(kBlock), 0, ctx->stream, ctx->q, bounce);
-    ev_end(ctx);
+    ctx->shadeRun[bounce] = true;
     HIPCHK(hipGetLastError());
     return RT_OK;
 }
@@ -635,9 +653,10 @@ extern "C" int rt_debug_set_rays(RtCtx* ctx, int32_t bounce, const RtRay* in, in
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (n > 0) {
         HIPCHK(hipMemcpy(ctx->dRayIO, in, sizeof(RtRay) * (size_t)n, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_import_rays, grid_for(n), dim3(kBlock), 0, ctx->stream, ctx->q, ctx->dRayIO, n);
+        hipLaunchKernelGGL(k_import_rays, grid_for(n), dim3(kBlock), 0, ctx->stream, ctx->q, ctx->dRayIO, n, bounce & 1);
     }
     hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, ctx->stream, ctx->q.nRays + bounce, n);
+    memset(ctx->shadeRun, 0, sizeof ctx->shadeRun); ctx->generated = false;   // injected queue: scan state must be re-armed
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return RT_OK;

@@ -15,8 +15,9 @@
 //    reference's 128-byte AoS Ray updated in place in global memory.
 //  * Schedule S1 of SURVEY.md §8(c): queue slot g is shaded with RNG stream seeds[g] and
 //    survivors keep their relative order.  The reference's global atomic_inc/atomic_dec
-//    counters become per-wave __ballot masks + popcount prefix (k_shade), one ordered
-//    scan over the wave counts (k_scan) and a scatter (k_compact): deterministic.
+//    counters become per-wave __ballot masks + popcount prefix inside k_shade and a
+//    single-pass ordered scan across workgroups (decoupled look-back): survivors are
+//    written straight to their final, stable queue position — deterministic, one kernel.
 //  * The traversal stack lives in LDS (one column per lane, conflict-free); the ray
 //    lives in registers; results are written once.
 //  * Float discipline = oracle/oracle.c header: IEEE + - * /, sqrt; dot/cross as the fma
@@ -53,15 +54,13 @@ struct DevScene {
     int32_t nLights, nPrims, nBlas;
 };
 struct DevQueues {
-    // live queue (compacted), capacity nPix
-    float4* O; float4* D; float4* inten; uint2* meta; float4* hit;
-    // per-slot staging written by shade (uncompacted)
-    float4* tO; float4* tD; float4* tInten; uint2* tMeta;
-    float4* tsA; float4* tsB; float4* tsC;
+    // ray queues (compacted), capacity nPix each; bounce b lives in set b & 1 (shade reads one, writes the other)
+    float4* O[2]; float4* D[2]; float4* inten[2]; uint2* meta[2];
+    float4* hit;       // {t, primIdx, u, v} of the queue extend() just traced
     // shadow queue (compacted), capacity max_bounces * nPix
     float4* sA; float4* sB; float4* sC;
-    unsigned long long* extMask; unsigned long long* shMask;
-    uint32_t* extBase; uint32_t* shBase;
+    // single-pass scan state of k_shade, one set per bounce parity: [1 + t] = status of tile t
+    unsigned long long* tile[2];
     int32_t* nRays;    // [RT_MAX_BOUNCES+2]  rays entering bounce b
     int32_t* nShadow;  // [RT_MAX_BOUNCES+2]  shadow rays of bounce b occupy [nShadow[b], nShadow[b+1])
     int32_t* cursor;   // [2*(RT_MAX_BOUNCES+2)] work-queue heads of the persistent kernels (extend: [b], connect: [9+b])
@@ -458,14 +457,15 @@ RT_FORCEINLINE void primary_ray(const RtCamera& cam, int x, int y, int W, int H,
 __global__ __launch_bounds__(kBlock) void k_generate(DevQueues q, RtCamera cam, int aa)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (threadIdx.x == 0) q.tile[0][1 + blockIdx.x] = 0ull;   // arm shade(0)'s scan
     if (i >= q.nPix) return;
     const int idx = q.firstPixel + i;
     uint32_t seed = q.seeds[i];
     float4 O, D;
     primary_ray(cam, idx % q.width, idx / q.width, q.width, q.height, aa, seed, O, D);
     q.seeds[i] = seed;
-    q.O[i] = O; q.D[i] = D; q.inten[i] = splat(1.0f);
-    q.meta[i] = make_uint2((uint32_t)idx, kMetaLastSpec); // bounces 0, inside 0, lastSpecular 1
+    q.O[0][i] = O; q.D[0][i] = D; q.inten[0][i] = splat(1.0f);
+    q.meta[0][i] = make_uint2((uint32_t)idx, kMetaLastSpec); // bounces 0, inside 0, lastSpecular 1
 }
 
 // ------------------------------------------------------------------ k_extend (variant 0: one ray per lane)
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int
     WorkCtr wc = { 0, 0, 0, 0 };
     uint32_t rays = 0;
     if (i < n) {
-        const float4 O = q.O[i], D = q.D[i];
+        const float4 O = q.O[bounce & 1][i], D = q.D[bounce & 1][i];
         TRay r;
         r.ox = O.x; r.oy = O.y; r.oz = O.z; r.dx = D.x; r.dy = D.y; r.dz = D.z;
         r.rx = 1.0f / D.x; r.ry = 1.0f / D.y; r.rz = 1.0f / D.z;
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
                 if (slot < 0 && idx < chunkEnd) {
                     float4 O, D; float tmax;
                     if (OCC) { const float4 a = q.sA[qFirst + idx], b = q.sB[qFirst + idx]; O = a; D = b; tmax = a.w; }
-                    else { O = q.O[idx]; D = q.D[idx]; tmax = kFar; }
+                    else { O = q.O[b0 & 1][idx]; D = q.D[b0 & 1][idx]; tmax = kFar; }
                     // transformRay (tlas.cl:3-8) of the single instance, same arithmetic as traverse_instance
                     const float4 Dv = mk4(D.x, D.y, D.z, 0.0f), Ov = mk4(O.x, O.y, O.z, 0.0f);
                     r.dx = dot3(mk4(T[0], T[1], T[2], 0), Dv); r.dy = dot3(mk4(T[4], T[5], T[6], 0), Dv); r.dz = dot3(mk4(T[8], T[9], T[10], 0), Dv);
@@ -791,94 +791,119 @@ RT_FORCEINLINE float4 shade_hit(const DevScene& sc, const DevVariant& var, SRay&
     return splat(0.0f);
 }
 
-// ------------------------------------------------------------------ k_shade
+// ------------------------------------------------------------------ k_shade (single pass, stable compaction)
+// Tile status word of the decoupled look-back scan: [63:62] flag (0 empty, 1 aggregate, 2 inclusive
+// prefix), [61:31] extension-ray count, [30:0] shadow-ray count.  Flag and payload travel in ONE 8-byte
+// word written/read with agent-scope atomics (L2-coherent across XCDs), so no separate fence is needed.
+static constexpr unsigned long long kTileAgg = 1ull << 62, kTilePrefix = 2ull << 62;
+RT_FORCEINLINE unsigned long long tile_pack(unsigned long long flag, uint32_t e, uint32_t s) { return flag | ((unsigned long long)e << 31) | (unsigned long long)s; }
+RT_FORCEINLINE uint32_t tile_ext(unsigned long long v) { return (uint32_t)((v >> 31) & 0x7fffffffull); }
+RT_FORCEINLINE uint32_t tile_sh(unsigned long long v) { return (uint32_t)(v & 0x7fffffffull); }
+
+// Persistent workgroups, static round-robin tiles: workgroup g shades tiles g, g+G, g+2G, ... in increasing
+// order (tile = 256 consecutive queue slots).  A tile's look-back only waits for tiles with smaller ids, and
+// those belong to workgroups of the same launch that process their own tiles in increasing order, so by
+// induction over the tile id every wait ends as long as the G workgroups can be co-resident — the host launches
+// G <= 4 per CU, half of what this kernel's registers/LDS admit, and uses no ticket atomics (8,100 tickets on
+// one word cost ~90 us per launch on this chip, more than the shading itself).
 template <bool NEE>
 __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevQueues q, DevVariant var, int bounce)
 {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ uint32_t sWaveE[kBlock / 64], sWaveS[kBlock / 64], sBaseE, sBaseS;
+    const int cur = bounce & 1, nxt = cur ^ 1;
+    unsigned long long* state = q.tile[cur];
     const int n = q.nRays[bounce];
-    ExtRay ext; ext.valid = false;
-    ShadowOut sh; sh.valid = false;
-    if (i < n) {
-        const float4 hit = q.hit[i];
-        const uint2 meta = q.meta[i];
-        SRay ray;
-        ray.O = q.O[i]; ray.D = q.D[i]; ray.inten = q.inten[i];
-        ray.t = hit.x; ray.prim = __float_as_int(hit.y); ray.u = hit.z; ray.v = hit.w;
-        ray.pixel = (int)meta.x; ray.bounces = (int)(meta.y & kMetaBounceMask);
-        ray.inside = (meta.y & kMetaInside) != 0; ray.lastSpec = (meta.y & kMetaLastSpec) != 0;
-        if (ray.prim == -1) { // wavefront.cl:109-112, sky = skydome.cl:7
-            float4 c = mul4(ray.inten, mk4(0.0784f, 0.0941f, 0.3215f, 0.0f));
-            q.accum[ray.pixel] = add4(q.accum[ray.pixel], c);
-        } else {
-            // what extend() leaves in the ray (wavefront.cl:69-72)
-            ray.I = add4(ray.O, muls(ray.D, ray.t));
-            ray.N = prim_normal(sc.prims + ray.prim, ray.I);
-            if (dot4(ray.N, neg4(ray.D)) < 0) ray.N = muls(ray.N, -1.0f);
-            uint32_t seed = q.seeds[i];
-            float4 color = shade_hit<NEE>(sc, var, ray, seed, ext, sh);
-            q.seeds[i] = seed;
-            color = firefly(var.fireflies, color);
-            // one path per pixel and launch: the add is race-free; adding an exact zero is skipped
-            if (color.x != 0.0f || color.y != 0.0f || color.z != 0.0f || color.w != 0.0f)
-                q.accum[ray.pixel] = add4(q.accum[ray.pixel], color);
-            if (ext.valid && ext.bounces <= RT_MAX_BOUNCES) { // wavefront.cl:129
-                q.tO[i] = ext.O; q.tD[i] = ext.D; q.tInten[i] = ext.inten;
-                q.tMeta[i] = make_uint2((uint32_t)ray.pixel, (uint32_t)ext.bounces | (ext.inside ? kMetaInside : 0u) | (ext.lastSpec ? kMetaLastSpec : 0u));
-            } else ext.valid = false;
-            if (sh.valid) { q.tsA[i] = sh.a; q.tsB[i] = sh.b; q.tsC[i] = sh.c; }
+    if (n <= 0) { // empty queue: still publish the (empty) next queue
+        if (blockIdx.x == 0 && threadIdx.x == 0) { q.nRays[bounce + 1] = 0; q.nShadow[bounce + 1] = q.nShadow[bounce]; }
+        return;
+    }
+    const uint32_t numTiles = (uint32_t)((n + kBlock - 1) / kBlock);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int shadowBase = q.nShadow[bounce];
+
+    for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+        const int i = (int)tile * kBlock + threadIdx.x;
+        if (threadIdx.x == 0) q.tile[nxt][1 + tile] = 0ull;     // arm shade(bounce+1)'s scan (its queue is never longer)
+
+        ExtRay ext; ext.valid = false;
+        ShadowOut sh; sh.valid = false;
+        int pixel = 0;
+        if (i < n) {
+            const float4 hit = q.hit[i];
+            const uint2 meta = q.meta[cur][i];
+            SRay ray;
+            ray.O = q.O[cur][i]; ray.D = q.D[cur][i]; ray.inten = q.inten[cur][i];
+            ray.t = hit.x; ray.prim = __float_as_int(hit.y); ray.u = hit.z; ray.v = hit.w;
+            ray.pixel = (int)meta.x; ray.bounces = (int)(meta.y & kMetaBounceMask);
+            ray.inside = (meta.y & kMetaInside) != 0; ray.lastSpec = (meta.y & kMetaLastSpec) != 0;
+            pixel = ray.pixel;
+            if (ray.prim == -1) { // wavefront.cl:109-112, sky = skydome.cl:7
+                float4 c = mul4(ray.inten, mk4(0.0784f, 0.0941f, 0.3215f, 0.0f));
+                q.accum[ray.pixel] = add4(q.accum[ray.pixel], c);
+            } else {
+                // what extend() leaves in the ray (wavefront.cl:69-72)
+                ray.I = add4(ray.O, muls(ray.D, ray.t));
+                ray.N = prim_normal(sc.prims + ray.prim, ray.I);
+                if (dot4(ray.N, neg4(ray.D)) < 0) ray.N = muls(ray.N, -1.0f);
+                uint32_t seed = q.seeds[i];
+                float4 color = shade_hit<NEE>(sc, var, ray, seed, ext, sh);
+                q.seeds[i] = seed;
+                color = firefly(var.fireflies, color);
+                // one path per pixel and launch: the add is race-free; adding an exact zero is skipped
+                if (color.x != 0.0f || color.y != 0.0f || color.z != 0.0f || color.w != 0.0f)
+                    q.accum[ray.pixel] = add4(q.accum[ray.pixel], color);
+                if (!(ext.valid && ext.bounces <= RT_MAX_BOUNCES)) ext.valid = false;   // wavefront.cl:129
+            }
         }
-    }
-    // wave-level compaction votes (replaces atomic_inc on numOutRays / shadowRays)
-    const unsigned long long em = __ballot(ext.valid), sm = __ballot(sh.valid);
-    if ((threadIdx.x & 63) == 0) {
-        const int w = i >> 6;
-        if (w * 64 < n) { q.extMask[w] = em; q.shMask[w] = sm; }
-    }
-}
-
-// ------------------------------------------------------------------ k_scan: ordered prefix over the wave votes
-__global__ __launch_bounds__(1024) void k_scan(DevQueues q, int bounce)
-{
-    __shared__ uint32_t sE[1024], sS[1024];
-    const int n = q.nRays[bounce];
-    const int nW = (n + 63) >> 6;
-    const int per = (nW + 1023) / 1024;
-    const int w0 = threadIdx.x * per, w1 = min(w0 + per, nW);
-    uint32_t e = 0, s = 0;
-    for (int w = w0; w < w1; w++) { e += __popcll(q.extMask[w]); s += __popcll(q.shMask[w]); }
-    sE[threadIdx.x] = e; sS[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
-        uint32_t ae = threadIdx.x >= off ? sE[threadIdx.x - off] : 0, as = threadIdx.x >= off ? sS[threadIdx.x - off] : 0;
+        // wave votes + ordered scan across tiles (replaces atomic_inc on numOutRays / shadowRays, wavefront.cl:131,136)
+        const unsigned long long em = __ballot(ext.valid), sm = __ballot(sh.valid);
+        if (lane == 0) { sWaveE[wave] = (uint32_t)__popcll(em); sWaveS[wave] = (uint32_t)__popcll(sm); }
         __syncthreads();
-        sE[threadIdx.x] += ae; sS[threadIdx.x] += as;
+        if (wave == 0) {
+            uint32_t aggE = 0, aggS = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; w++) { aggE += sWaveE[w]; aggS += sWaveS[w]; }
+            uint32_t preE = 0, preS = 0;
+            if (tile > 0) {
+                if (lane == 0) __hip_atomic_store(&state[1 + tile], tile_pack(kTileAgg, aggE, aggS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int top = (int)tile - 1;                 // look back 64 predecessors per step
+                for (;;) {
+                    const int t = top - lane;
+                    unsigned long long v = kTilePrefix;  // lanes before tile 0 read as "prefix 0"
+                    if (t >= 0) {
+                        v = __hip_atomic_load(&state[1 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        while ((v >> 62) == 0ull) { __builtin_amdgcn_s_sleep(2); v = __hip_atomic_load(&state[1 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    }
+                    const unsigned long long isPre = __ballot((v >> 62) == 2ull);
+                    const int stop = isPre ? __ffsll((long long)isPre) - 1 : 64;   // nearest predecessor with an inclusive prefix
+                    uint32_t e = lane <= stop ? tile_ext(v) : 0u, s2 = lane <= stop ? tile_sh(v) : 0u;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) { e += __shfl_xor(e, off, 64); s2 += __shfl_xor(s2, off, 64); }
+                    preE += e; preS += s2;
+                    if (isPre) break;
+                    top -= 64;
+                }
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&state[1 + tile], tile_pack(kTilePrefix, preE + aggE, preS + aggS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sBaseE = preE; sBaseS = preS;
+                if (tile == numTiles - 1) { q.nRays[bounce + 1] = (int)(preE + aggE); q.nShadow[bounce + 1] = shadowBase + (int)(preS + aggS); }
+            }
+        }
         __syncthreads();
-    }
-    uint32_t be = sE[threadIdx.x] - e, bs = sS[threadIdx.x] - s;
-    for (int w = w0; w < w1; w++) {
-        q.extBase[w] = be; q.shBase[w] = bs;
-        be += __popcll(q.extMask[w]); bs += __popcll(q.shMask[w]);
-    }
-    if (threadIdx.x == 1023) { q.nRays[bounce + 1] = (int)sE[1023]; q.nShadow[bounce + 1] = q.nShadow[bounce] + (int)sS[1023]; }
-}
-
-// ------------------------------------------------------------------ k_compact: stable scatter of survivors
-__global__ __launch_bounds__(kBlock) void k_compact(DevQueues q, int bounce)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const int n = q.nRays[bounce];
-    if (i >= n) return;
-    const int w = i >> 6, lane = i & 63;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const unsigned long long em = q.extMask[w], sm = q.shMask[w];
-    if ((em >> lane) & 1ull) {
-        const uint32_t dst = q.extBase[w] + __popcll(em & below);
-        q.O[dst] = q.tO[i]; q.D[dst] = q.tD[i]; q.inten[dst] = q.tInten[i]; q.meta[dst] = q.tMeta[i];
-    }
-    if ((sm >> lane) & 1ull) {
-        const uint32_t dst = (uint32_t)q.nShadow[bounce] + q.shBase[w] + __popcll(sm & below);
-        q.sA[dst] = q.tsA[i]; q.sB[dst] = q.tsB[i]; q.sC[dst] = q.tsC[i];
+        uint32_t baseE = sBaseE, baseS = sBaseS + (uint32_t)shadowBase;
+        for (int w = 0; w < wave; w++) { baseE += sWaveE[w]; baseS += sWaveS[w]; }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (ext.valid) {
+            const uint32_t dst = baseE + (uint32_t)__popcll(em & below);
+            q.O[nxt][dst] = ext.O; q.D[nxt][dst] = ext.D; q.inten[nxt][dst] = ext.inten;
+            q.meta[nxt][dst] = make_uint2((uint32_t)pixel, (uint32_t)ext.bounces | (ext.inside ? kMetaInside : 0u) | (ext.lastSpec ? kMetaLastSpec : 0u));
+        }
+        if (sh.valid) {
+            const uint32_t dst = baseS + (uint32_t)__popcll(sm & below);
+            q.sA[dst] = sh.a; q.sB[dst] = sh.b; q.sC[dst] = sh.c;
+        }
+        __syncthreads();   // LDS words are reused by the next tile
     }
 }
 
@@ -942,8 +967,9 @@ __global__ void k_export_rays(DevScene sc, DevQueues q, int bounce, RtRay* out)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= q.nRays[bounce]) return;
     RtRay r;
-    const float4 O = q.O[i], D = q.D[i], hit = q.hit[i], inten = q.inten[i];
-    const uint2 meta = q.meta[i];
+    const int set = bounce & 1;
+    const float4 O = q.O[set][i], D = q.D[set][i], hit = q.hit[i], inten = q.inten[set][i];
+    const uint2 meta = q.meta[set][i];
     float4 rD = mk4(1.0f / D.x, 1.0f / D.y, 1.0f / D.z, 1.0f / D.w);
     float4 I = splat(0.0f), N = splat(0.0f);
     const int prim = __float_as_int(hit.y);
@@ -959,14 +985,14 @@ __global__ void k_export_rays(DevScene sc, DevQueues q, int bounce, RtRay* out)
     r._pad0[0] = r._pad0[1] = 0; r.u = hit.z; r.v = hit.w; r._pad1 = 0;
     out[i] = r;
 }
-__global__ void k_import_rays(DevQueues q, const RtRay* in, int n)
+__global__ void k_import_rays(DevQueues q, const RtRay* in, int n, int set)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const RtRay r = in[i];
-    q.O[i] = ld4(r.O); q.D[i] = ld4(r.D); q.inten[i] = ld4(r.intensity);
+    q.O[set][i] = ld4(r.O); q.D[set][i] = ld4(r.D); q.inten[set][i] = ld4(r.intensity);
     q.hit[i] = mk4(r.t, __int_as_float(r.primIdx), r.u, r.v);
-    q.meta[i] = make_uint2((uint32_t)r.pixelIdx, (uint32_t)r.bounces | (r.inside ? kMetaInside : 0u) | (r.lastSpecular ? kMetaLastSpec : 0u));
+    q.meta[set][i] = make_uint2((uint32_t)r.pixelIdx, (uint32_t)r.bounces | (r.inside ? kMetaInside : 0u) | (r.lastSpecular ? kMetaLastSpec : 0u));
 }
 __global__ void k_set_count(int32_t* p, int32_t v) { *p = v; }
 
