@@ -124,6 +124,11 @@ int rt_reset_counters(RtCtx* ctx);
 int rt_read_stage_times(RtCtx* ctx, RtStageTimes* out);
 int rt_reset_stage_times(RtCtx* ctx);
 
+/* Renderer::PostProc() + SaveFrame() (renderer.cpp:95-124,303-308; src/cl/postproc.cl): prep (divide by `frames`, clamp 1),
+ * vignetting if vignette > 0, gammaCorr if gamma != 1, chromatic if chromatic > 0, then min(color,1).  Writes the float
+ * image (float4[width*height], w = 1) and/or the 8-bit image (RGBA, bytes (uchar)(c*255) as SaveImageF); either may be NULL. */
+int rt_postproc(RtCtx* ctx, int32_t frames, float vignette, float gamma, float chromatic, RtFloat4* outF32, uint8_t* outRGBA8);
+
 /* ---- stage-level entry points (one kernel of the reference each), used by the parity
  * tests to feed identical inputs to one stage at a time ------------------------------ */
 int rt_stage_begin_frame(RtCtx* ctx);                                           /* renderer.cpp:66-69   */
@@ -139,7 +144,10 @@ int rt_debug_set_rays(RtCtx* ctx, int32_t bounce, const RtRay* in, int32_t n);
  * radiance the ray carries if unoccluded. */
 typedef struct RtShadowRecord { float ox, oy, oz, tmax; float lx, ly, lz; int32_t pixelIdx; RtFloat4 radiance; } RtShadowRecord;
 int rt_debug_get_shadow(RtCtx* ctx, int32_t firstBounce, int32_t lastBounce, RtShadowRecord* out, int32_t capacity, int32_t* n);
-int rt_debug_get_steps(RtCtx* ctx, int32_t* out, int32_t capacity, int32_t* n);  /* per-ray `steps` of the last extend */
+/* Per-ray `steps` (the value the reference's heat map shows, wavefront.cl:66-67) of the last extend; recording is off
+ * by default (it costs 4 B written per ray) and is switched on with rt_debug_enable_steps(ctx, 1). */
+int rt_debug_enable_steps(RtCtx* ctx, int32_t on);
+int rt_debug_get_steps(RtCtx* ctx, int32_t* out, int32_t capacity, int32_t* n);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,10 @@ int rth_add_quad(RthScene* s, const float v0[3], const float v1[3], const float 
                  const char* material, int flipNormal);                                       /* scene.cpp:152-156, default uvs */
 /* n x AddTriangle; verts is n*9 floats (v0,v1,v2), uvs n*6 floats or NULL (all zero). */
 int rth_add_triangles(RthScene* s, const float* verts, const float* uvs, int n, const char* material, int flipNormal);
+/* Scene::LoadModel (scene.cpp:178-243): OBJ (+MTL map_Kd names); returns the number of triangles added or -1. */
+int rth_load_model(RthScene* s, const char* filename, const char* defaultMaterial, const float pos[3], int forceDefaultMat);
+/* SaveImageF (template/template.cpp:1629-1644): float4 image -> 8-bit RGB PNG, bytes (uchar)(min(c,1)*255). */
+int rth_save_png(const char* file, int width, int height, const RtFloat4* data);
 /* BVH2::BuildBLAS(true, startIdx) with bvh2->alpha = alpha (bvh.cpp:46-82). */
 int rth_build_blas(RthScene* s, int startIdx, float alpha);
 int rth_build_bvh4(RthScene* s);            /* new BVH4(*bvh2) (scene.cpp:71)                    */
@@ -70,6 +74,7 @@ int  rth_renderer_set_camera(RthRenderer* r, const float origin[3], const float 
 int  rth_renderer_tick(RthRenderer* r, int frames);                       /* Renderer::Tick x frames */
 int  rth_renderer_read(RthRenderer* r, RtFloat4* out, float* energy);     /* accumBuffer read-back + ComputeEnergy */
 int  rth_renderer_camera(RthRenderer* r, RtCamera* out);
+int  rth_renderer_save_frame(RthRenderer* r, const char* file);          /* Renderer::SaveFrame (renderer.cpp:303-308) */
 
 #ifdef __cplusplus
 }

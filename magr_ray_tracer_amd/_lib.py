@@ -59,16 +59,17 @@ MAX_BOUNCES = 7
 DEVICE_SYMBOLS = [
     "rt_last_error", "rt_device_count", "rt_create", "rt_destroy", "rt_upload_scene", "rt_set_seeds", "rt_seed_default",
     "rt_get_seeds", "rt_bind_accum", "rt_accum_device_ptr", "rt_stream", "rt_reset", "rt_render", "rt_synchronize", "rt_focus",
-    "rt_read_accum", "rt_read_counters", "rt_reset_counters", "rt_read_stage_times", "rt_reset_stage_times",
+    "rt_read_accum", "rt_postproc", "rt_read_counters", "rt_reset_counters", "rt_read_stage_times", "rt_reset_stage_times",
     "rt_stage_begin_frame", "rt_stage_generate", "rt_stage_extend", "rt_stage_shade", "rt_stage_connect",
-    "rt_debug_get_rays", "rt_debug_set_rays", "rt_debug_get_shadow", "rt_debug_get_steps"]
+    "rt_debug_get_rays", "rt_debug_set_rays", "rt_debug_get_shadow", "rt_debug_enable_steps", "rt_debug_get_steps"]
 HOST_SYMBOLS = [
     "rth_last_error", "rth_scene_create", "rth_scene_destroy", "rth_add_material", "rth_add_texture", "rth_add_sphere",
     "rth_add_plane", "rth_add_triangle", "rth_add_quad", "rth_add_triangles", "rth_build_blas", "rth_build_bvh4",
     "rth_build_tlas", "rth_set_instance_transform", "rth_primitives", "rth_materials", "rth_textures", "rth_lights",
     "rth_bvh2_nodes", "rth_bvh4_nodes", "rth_prim_idx", "rth_tlas_nodes", "rth_blas_nodes", "rth_bvh_stats", "rth_camera",
     "rth_renderer_create", "rth_renderer_destroy", "rth_renderer_init", "rth_renderer_set_camera", "rth_renderer_tick",
-    "rth_renderer_read", "rth_renderer_camera", "rth_seed_stream"]
+    "rth_renderer_read", "rth_renderer_camera", "rth_seed_stream", "rth_load_model", "rth_save_png",
+    "rth_renderer_save_frame"]
 
 _dev = None
 _host = None
@@ -111,6 +112,7 @@ def device_lib():
         lib.rt_focus.argtypes = [vp, i32, i32, vp, C.POINTER(C.c_float)]
         lib.rt_read_accum.argtypes = [vp, vp]
         lib.rt_read_counters.argtypes = [vp, vp]
+        lib.rt_postproc.argtypes = [vp, i32, C.c_float, C.c_float, C.c_float, vp, vp]
         lib.rt_reset_counters.argtypes = [vp]
         lib.rt_read_stage_times.argtypes = [vp, vp]
         lib.rt_reset_stage_times.argtypes = [vp]
@@ -123,6 +125,7 @@ def device_lib():
         lib.rt_debug_set_rays.argtypes = [vp, i32, vp, i32]
         lib.rt_debug_get_shadow.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
         lib.rt_debug_get_steps.argtypes = [vp, vp, i32, C.POINTER(i32)]
+        lib.rt_debug_enable_steps.argtypes = [vp, i32]
         _dev = lib
     return _dev
 
@@ -163,6 +166,9 @@ def host_lib():
         lib.rth_renderer_read.argtypes = [vp, vp, fp]
         lib.rth_renderer_camera.argtypes = [vp, vp]
         lib.rth_seed_stream.argtypes = [vp, C.c_int64, C.c_int64]
+        lib.rth_load_model.argtypes = [vp, cp, cp, fp, i32]
+        lib.rth_save_png.argtypes = [cp, i32, i32, vp]
+        lib.rth_renderer_save_frame.argtypes = [vp, cp]
         _host = lib
     return _host
 

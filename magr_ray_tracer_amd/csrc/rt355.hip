@@ -48,7 +48,9 @@ struct RtCtx {
     bool shadeRun[RT_MAX_BOUNCES + 1] = {};           // shade(b) launched since the last k_begin_frame
     bool generated = false;                           // generate launched since the last k_begin_frame
     int stackEntries = RT_BVH2_STACK, persistGrid = 0;
-    PersistTune tune{ 64, 20, 6 };
+    PersistTune tune{ 64, 20, 6, 8 };
+    float4* dPostF = nullptr; uchar4* dPostB = nullptr;   // post-processing outputs (lazy)
+    int32_t* dSteps = nullptr;   // per-ray `steps` buffer, only bound while rt_debug_enable_steps is on
     int shadeGrid = 1024;   // co-resident workgroups of k_shade (see the kernel's comment); set in rt_create
 };
 enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_COMPACT, ST_CONNECT, ST_ACCUM };
@@ -148,7 +150,9 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     QA(hit, n);
     QA(sA, nS); QA(sB, nS); QA(sC, nS);
     QA(nRays, RT_MAX_BOUNCES + 2); QA(nShadow, RT_MAX_BOUNCES + 2); QA(cursor, 2 * (RT_MAX_BOUNCES + 2));
-    QA(seeds, n); QA(accum, (size_t)c.width * c.height); QA(steps, n);
+    QA(seeds, n); QA(accum, (size_t)c.width * c.height);
+    if (rc == RT_OK) rc = dalloc(bag, &ctx->dSteps, n);
+    q.steps = nullptr;
     QA(ctrExtend, (size_t)ctx->gridMax * 5); QA(ctrConnect, (size_t)ctx->gridMax * 5);
 #undef QA
     if (rc == RT_OK) rc = dalloc(bag, &ctx->dFocus, 1);
@@ -175,6 +179,8 @@ extern "C" int rt_destroy(RtCtx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_bag(ctx->sceneAllocs); free_bag(ctx->queueAllocs);
     if (ctx->dRayIO) (void)hipFree(ctx->dRayIO);
+    if (ctx->dPostF) (void)hipFree(ctx->dPostF);
+    if (ctx->dPostB) (void)hipFree(ctx->dPostB);
     for (auto& e : ctx->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -341,11 +347,11 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         HIPCHK(hipGetDeviceProperties(&prop, ctx->cfg.device));
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_persist<false>, kBlock, stack_bytes(ctx)));
         ctx->persistGrid = std::min(ctx->gridMax, std::max(1, perCU) * prop.multiProcessorCount);
-        if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner[,blocksPerCU]" (tuning aid)
-            int a = 0, b = 0, c = 0, d = 0;
-            int k = sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &d);
-            if (k >= 3 && a > 0 && b > 0 && b <= 64 && c > 0) ctx->tune = PersistTune{ a, b, c };
-            if (k == 4 && d > 0) ctx->persistGrid = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount);
+        if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner,leafK[,blocksPerCU]" (tuning aid)
+            int a = 0, b = 0, c = 0, l = 0, d = 0;
+            int k = sscanf(t, "%d,%d,%d,%d,%d", &a, &b, &c, &l, &d);
+            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = PersistTune{ a, b, c, l };
+            if (k == 5 && d > 0) ctx->persistGrid = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount);
         }
     }
     ctx->sc = sc;
@@ -686,14 +692,40 @@ extern "C" int rt_debug_get_shadow(RtCtx* ctx, int32_t b0, int32_t b1, RtShadowR
     }
     return RT_OK;
 }
+extern "C" int rt_debug_enable_steps(RtCtx* ctx, int32_t on)
+{
+    if (!ctx) return fail(RT_E_INVALID, "rt_debug_enable_steps: null context");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->q.steps = on ? ctx->dSteps : nullptr;
+    return RT_OK;
+}
 extern "C" int rt_debug_get_steps(RtCtx* ctx, int32_t* out, int32_t capacity, int32_t* n)
 {
     if (!ctx || !n) return fail(RT_E_INVALID, "rt_debug_get_steps: bad argument");
+    if (!ctx->q.steps) return fail(RT_E_INVALID, "rt_debug_get_steps: call rt_debug_enable_steps(ctx, 1) before the extend stage");
     HIPCHK(hipSetDevice(ctx->cfg.device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *n = ctx->nPix;
     if (!out) return RT_OK;
     if (capacity < ctx->nPix) return fail(RT_E_INVALID, "rt_debug_get_steps: capacity too small");
-    HIPCHK(hipMemcpy(out, ctx->q.steps, sizeof(int32_t) * (size_t)ctx->nPix, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, ctx->dSteps, sizeof(int32_t) * (size_t)ctx->nPix, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// ---- post-processing chain (renderer.cpp:95-124 PostProc, :303-308 SaveFrame) ----------------------------------------
+extern "C" int rt_postproc(RtCtx* ctx, int32_t frames, float vignette, float gamma, float chromatic, RtFloat4* outF32, uint8_t* outRGBA8)
+{
+    if (!ctx) return fail(RT_E_INVALID, "rt_postproc: null context");
+    if (frames <= 0) return fail(RT_E_INVALID, "rt_postproc: frames must be > 0 (it is the divisor of prep())");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    const size_t px = (size_t)ctx->cfg.width * ctx->cfg.height;
+    if (!ctx->dPostF) { HIPCHK(hipMalloc((void**)&ctx->dPostF, px * sizeof(float4))); HIPCHK(hipMalloc((void**)&ctx->dPostB, px * 4)); }
+    PostParams pp{ 1 / (float)frames, vignette, gamma, chromatic, ctx->cfg.width, ctx->cfg.height };
+    hipLaunchKernelGGL(k_postproc, grid_for((int)px), dim3(kBlock), 0, ctx->stream, (const float4*)ctx->q.accum, ctx->dPostF, ctx->dPostB, pp);
+    HIPCHK(hipGetLastError());
+    if (outF32) HIPCHK(hipMemcpyAsync(outF32, ctx->dPostF, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    if (outRGBA8) HIPCHK(hipMemcpyAsync(outRGBA8, ctx->dPostB, px * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ev_collect(ctx);
     return RT_OK;
 }

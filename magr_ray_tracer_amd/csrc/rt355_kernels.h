@@ -504,12 +504,12 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int
 // all its lanes idle), so the grid always drains.
 // Work distribution: the first chunk of every wave is static (chunk id = global wave id, no atomic, so the
 // launch does not start with thousands of waves hammering one counter); further chunks are dequeued.
-struct PersistTune { int chunk, refill, inner; };   // rays per dequeue, idle lanes that trigger a top-up, events between checks
+struct PersistTune { int chunk, refill, inner, leafK; };   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path
 
 template <bool OCC>
 __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues q, int b0, int b1, int renderBVH, PersistTune tune)
 {
-    const int kChunk = tune.chunk, kRefill = tune.refill, kInner = tune.inner;
+    const int kChunk = tune.chunk, kRefill = tune.refill, kInner = tune.inner, kLeafK = tune.leafK;
     extern __shared__ uint32_t stk[];
     const int lane = threadIdx.x & 63;
     // queue window: extend -> rays [0, nRays[b0]); connect -> shadow rays [nShadow[b0], nShadow[b1+1])
@@ -566,9 +566,16 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
         }
 #pragma unroll 1
         for (int it = 0; it < kInner; it++) {
-            if (slot >= 0) {
-                bool done = false, occluded = false;
-                if (cur & kLeafBit) {
+            // One event per lane and iteration, but the wave issues only ONE of the two code paths: triangle tests
+            // are held back until kLeafK lanes sit on a leaf (or no lane has a box test left), so neither path runs
+            // with a handful of lanes while the rest of the wave waits (the per-ray event order is unchanged).
+            const bool act = slot >= 0, atLeaf = act && (cur & kLeafBit) != 0u;
+            const unsigned long long lm = __ballot(atLeaf), im = __ballot(act && !atLeaf);
+            if ((lm | im) == 0ull) break;
+            const bool doLeaf = im == 0ull || __popcll(lm) >= kLeafK;
+            bool done = false, occluded = false;
+            if (doLeaf) {
+                if (atLeaf) {
                     const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
                     wc.prim++;
                     test_tri_packed(sc, first, r);
@@ -576,32 +583,32 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
                     else if (count > 1) cur = kLeafBit | ((count - 1) << 24) | (first + 1);
                     else if (sp == 0) done = true;
                     else cur = STK(--sp);
+                }
+            } else if (act && !atLeaf) {
+                wc.node++;
+                const float4* p = sc.pairs + (size_t)cur * 4;
+                const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                float d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
+                float d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
+                uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
+                if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t e = e1; e1 = e2; e2 = e; }
+                if (d1 >= tLight) {
+                    if (sp == 0) done = true;
+                    else cur = STK(--sp);
                 } else {
-                    wc.node++;
-                    const float4* p = sc.pairs + (size_t)cur * 4;
-                    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                    float d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
-                    float d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
-                    uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
-                    if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t e = e1; e1 = e2; e2 = e; }
-                    if (d1 >= tLight) {
-                        if (sp == 0) done = true;
-                        else cur = STK(--sp);
-                    } else {
-                        steps++;
-                        cur = e1;
-                        if (d2 < tLight) { STK(sp) = e2; sp++; steps++; }
-                    }
+                    steps++;
+                    cur = e1;
+                    if (d2 < tLight) { STK(sp) = e2; sp++; steps++; }
                 }
-                if (done) {
-                    if (OCC) { if (occluded) q.sC[qFirst + slot] = splat(0.0f); }
-                    else {
-                        q.hit[slot] = mk4(r.t, __int_as_float(r.prim), r.u, r.v);
-                        if (q.steps) q.steps[slot] = steps;
-                        if (renderBVH) q.accum[q.firstPixel + slot] = splat((float)(uint32_t)steps / 255.f);
-                    }
-                    slot = -1;
+            }
+            if (done) {
+                if (OCC) { if (occluded) q.sC[qFirst + slot] = splat(0.0f); }
+                else {
+                    q.hit[slot] = mk4(r.t, __int_as_float(r.prim), r.u, r.v);
+                    if (q.steps) q.steps[slot] = steps;
+                    if (renderBVH) q.accum[q.firstPixel + slot] = splat((float)(uint32_t)steps / 255.f);
                 }
+                slot = -1;
             }
         }
     }
@@ -959,6 +966,45 @@ __global__ void k_focus(DevScene sc, RtCamera cam, int x, int y, int W, int H, f
     WorkCtr wc = { 0, 0, 0, 0 };
     traverse_tlas<ACCEL, 0, false>(sc, r, stk, wc);
     *out = r.t;
+}
+
+// ------------------------------------------------------------------ post-processing (src/cl/postproc.cl)
+// The reference runs prep -> [vignetting] -> [gammaCorr] -> [chromatic] -> saveImage as separate full-frame
+// passes over two swap buffers (renderer.cpp:95-124, 303-308).  They are per-pixel streaming operations (chromatic
+// also reads the left neighbour), so one kernel evaluates the chain for a pixel and, when chromatic aberration is on,
+// for its left neighbour: 16 B read + 16 B written per pixel instead of up to 5 x 32 B.
+struct PostParams { float invFrames, vignette, gamma, chromatic; int width, height; };
+RT_FORCEINLINE float3 post_chain(const float4* accum, int idx, const PostParams& pp)
+{
+    const float4 a = accum[idx];
+    float3 c = make_float3(fminf(a.x * pp.invFrames, 1.0f), fminf(a.y * pp.invFrames, 1.0f), fminf(a.z * pp.invFrames, 1.0f)); // prep, postproc.cl:65-75
+    if (pp.vignette > 0) { // postproc.cl:18-32
+        const int x = idx % pp.width, y = idx / pp.width;
+        const float px = (float)x / (float)pp.width - 0.5f, py = (float)y / (float)pp.height - 0.5f;
+        float d = __fmaf_rn(py, py, px * px);                                    // length(float2): dot then sqrt (library rescaling
+        float len = d < 1.17549435e-38f ? sqrtf(__fmaf_rn(py * 0x1p+86f, py * 0x1p+86f, (px * 0x1p+86f) * (px * 0x1p+86f))) * 0x1p-86f : sqrtf(d); // branch for tiny)
+        float t = fminf(fmaxf(len, 0.0f), 1.0f);                                 // smoothstep(0,1,len) = t*t*fma(t,-2,3)
+        float vig = 1 - (t * t) * __fmaf_rn(t, -2.0f, 3.0f);
+        c = make_float3(__fmaf_rn(c.x * vig - c.x, pp.vignette, c.x), __fmaf_rn(c.y * vig - c.y, pp.vignette, c.y),
+                        __fmaf_rn(c.z * vig - c.z, pp.vignette, c.z));           // mix(a,b,s) = fma(b-a, s, a)
+    }
+    if (pp.gamma != 1.0f) c = make_float3(powf(c.x, pp.gamma), powf(c.y, pp.gamma), powf(c.z, pp.gamma)); // postproc.cl:34-40
+    return c;
+}
+__global__ __launch_bounds__(kBlock) void k_postproc(const float4* accum, float4* out, uchar4* rgba8, PostParams pp)
+{
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= pp.width * pp.height) return;
+    float3 c = post_chain(accum, idx, pp);
+    if (pp.chromatic > 0 && idx % pp.width != 0) { // postproc.cl:42-63
+        const float3 prev = post_chain(accum, idx - 1, pp);
+        const float o = pp.chromatic;
+        c = make_float3(c.x, c.y * (1 - o) + prev.y * o, c.z * (1 - 2 * o) + prev.z * 2 * o);
+    }
+    // display (target is RGBA8) + saveImage: min(color, 1) (postproc.cl:7-16,77-86); bytes as SaveImageF (template.cpp:1629-1644)
+    const float4 o4 = mk4(fminf(c.x, 1.0f), fminf(c.y, 1.0f), fminf(c.z, 1.0f), 1.0f);
+    if (out) out[idx] = o4;
+    if (rgba8) rgba8[idx] = make_uchar4((unsigned char)(o4.x * 255), (unsigned char)(o4.y * 255), (unsigned char)(o4.z * 255), 255);
 }
 
 // ------------------------------------------------------------------ debug import/export (parity tests)

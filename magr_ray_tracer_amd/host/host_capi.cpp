@@ -147,6 +147,19 @@ int rth_renderer_camera(RthRenderer* r, RtCamera* out) { GUARD(*out = r->r->came
 
 } // extern "C"
 
+extern "C" int rth_load_model(RthScene* s, const char* filename, const char* defaultMaterial, const float pos[3], int forceDefaultMat)
+{
+    if (!s || !filename || !defaultMaterial) { g_herr = "rth_load_model: null argument"; return -1; }
+    try { return s->scene.LoadModel(filename, defaultMaterial, pos ? f3(pos) : float3(0, 0, 0), forceDefaultMat != 0); }
+    catch (const std::exception& e) { g_herr = e.what(); return -1; }
+}
+extern "C" int rth_save_png(const char* file, int w, int h, const RtFloat4* data)
+{
+    if (!file || !data || w <= 0 || h <= 0) { g_herr = "rth_save_png: bad argument"; return -1; }
+    GUARD(SavePNG(file, w, h, data))
+}
+extern "C" int rth_renderer_save_frame(RthRenderer* r, const char* file) { GUARD(r->r->SaveFrame(file)) }
+
 // seeds[i] = (first+i+1)-th xorshift32 output from 0x12345678 — the reference's host seed loop
 // (src/renderer.cpp:195-196 over template/template.cpp:711,724-730).
 extern "C" int rth_seed_stream(uint32_t* out, int64_t first, int64_t n)

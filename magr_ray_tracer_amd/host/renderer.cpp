@@ -88,6 +88,14 @@ void Renderer::FocusCamera(int x, int y) // renderer.cpp:289-301
     if (t != RT_REALLYFAR) camera.cam.focalLength = t;
 }
 void Renderer::ReadAccum(RtFloat4* out) { check(rt_read_accum(ctx, out), "rt_read_accum"); }
+void Renderer::SaveFrame(const char* file) // renderer.cpp:303-308 after PostProc (:95-124)
+{
+    std::vector<RtFloat4> img((size_t)width * height);
+    // Tick() has already advanced settings->frames past the frame whose image is shown (renderer.cpp:49-53)
+    int shown = settings->frames > 1 ? settings->frames - 1 : 1;
+    check(rt_postproc(ctx, shown, vignet_strength, gamma_strength, chromatic_strength, img.data(), nullptr), "rt_postproc");
+    SavePNG(file, width, height, img.data());
+}
 void Renderer::ComputeEnergy() // renderer.cpp:126-140
 {
     std::vector<RtFloat4> px((size_t)width * height);

@@ -128,6 +128,9 @@ public:
                      bool flipNormal = false);
     int  AddTexture(const RtFloat4* texels, int width, int height, const std::string& name); // LoadTexture minus the file read
     int  MaterialIndex(const std::string& name);
+    bool HasMaterial(const std::string& name) const { return matMap_.count(name) != 0; }
+    // reference: Scene::LoadModel (scene.cpp:178-243), OBJ + MTL diffuse-texture names; returns the triangles added
+    int  LoadModel(const std::string& filename, const std::string& defaultMaterial, float3 pos = float3(0, 0, 0), bool forceDefaultMat = false);
     void BuildBVH4();
     std::vector<RtPrimitive>   primitives;
     std::vector<RtMaterial>    materials;
@@ -140,6 +143,9 @@ private:
     std::map<std::string, int> matMap_;
     int matIdx_ = 0;
 };
+
+// reference: SaveImageF (template/template.cpp:1629-1644) behind Renderer::SaveFrame (renderer.cpp:303-308)
+void SavePNG(const std::string& file, int w, int h, const RtFloat4* data);
 
 // reference: src/camera.h:7-122 (aspect = width/height is a run-time value here)
 class CameraManager {
@@ -176,6 +182,8 @@ public:
     void ComputeEnergy();              // renderer.cpp:126-140
     void FocusCamera(int x, int y);    // renderer.cpp:289-301
     void ReadAccum(RtFloat4* out);     // accumBuffer->CopyFromDevice()
+    void SaveFrame(const char* file);  // renderer.cpp:303-308 (PostProc chain + saveImage + SaveImageF)
+    float vignet_strength = 0, chromatic_strength = 0, gamma_strength = .9f;   // renderer.h:28-30
     Scene          scene;
     CameraManager  camera;
     RtSettings*    settings = nullptr;

@@ -102,6 +102,13 @@ class Device:
         self._chk(self._lib.rt_read_accum(self._h, _lib.ptr(out)))
         return out
 
+    def postproc(self, frames, vignette=0.0, gamma=0.9, chromatic=0.0):
+        """Renderer::PostProc + SaveFrame: returns (float image (H,W,4), RGBA8 image (H,W,4) uint8)."""
+        f = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        b = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        self._chk(self._lib.rt_postproc(self._h, int(frames), float(vignette), float(gamma), float(chromatic), _lib.ptr(f), _lib.ptr(b)))
+        return f, b
+
     def counters(self):
         c = np.zeros((), dtype=_lib.Counters)
         self._chk(self._lib.rt_read_counters(self._h, c.ctypes.data_as(C.c_void_p)))
@@ -157,6 +164,9 @@ class Device:
             self._chk(self._lib.rt_debug_get_shadow(self._h, b0, b1, _lib.ptr(out), n.value, C.byref(n)))
         return out
 
+    def enable_steps(self, on=True):
+        self._chk(self._lib.rt_debug_enable_steps(self._h, int(on)))
+
     def get_steps(self):
         n = C.c_int32(0)
         out = np.zeros(self.npix, dtype=np.int32)
@@ -199,6 +209,9 @@ class Renderer:
         e = C.c_float(0)
         self._chk(self._lib.rth_renderer_read(self._h, _lib.ptr(out), C.byref(e)))
         return out, float(e.value)
+
+    def SaveFrame(self, path):
+        self._chk(self._lib.rth_renderer_save_frame(self._h, str(path).encode()))
 
     def close(self):
         if self._h:

@@ -111,6 +111,12 @@ class Scene:
                                               material.encode(), int(flipNormal)))
         self.num_prims += v.shape[0]
 
+    # reference: Scene::LoadModel (scene.cpp:178-243)
+    def LoadModel(self, filename, defaultMaterial, pos=(0, 0, 0), forceDefaultMat=False):
+        n = self._chk(self._lib.rth_load_model(self._h, str(filename).encode(), defaultMaterial.encode(), _lib.fvec(pos), int(forceDefaultMat)))
+        self.num_prims += n
+        return n
+
     # reference: BVH2::BuildBLAS (bvh.cpp:46-82), bvh2->alpha = 1 -> plain SAH BVH, 0 -> full SBVH
     def BuildBLAS(self, startIdx=0, alpha=1.0):
         self._chk(self._lib.rth_build_blas(self._h, int(startIdx), float(alpha)))
@@ -152,3 +158,10 @@ def make_camera(width, height, origin, forward, fov=110.0, aperture=0.1, focalLe
     if rc < 0:
         raise RuntimeError(_lib.host_lib().rth_last_error().decode())
     return cam
+
+
+def save_png(path, image):
+    """SaveImageF (template/template.cpp:1629-1644): (H,W,4) float image -> 8-bit RGB PNG."""
+    a = np.ascontiguousarray(image, dtype=np.float32)
+    if _lib.host_lib().rth_save_png(str(path).encode(), a.shape[1], a.shape[0], _lib.ptr(a)) < 0:
+        raise RuntimeError(_lib.host_lib().rth_last_error().decode())

@@ -696,6 +696,41 @@ void orc_trace_normals(const OrcScene* sc, const OrcConfig* cfg, const RtCamera*
     }
 }
 
+/* ---------------------------------------------------------------- post-processing (src/cl/postproc.cl, renderer.cpp:95-124) */
+static void post_chain(const RtFloat4* accum, int idx, int W, int H, float invFrames, float vignette, float gamma, float out[3])
+{
+    float c[3] = { fminf(accum[idx].x * invFrames, 1.0f), fminf(accum[idx].y * invFrames, 1.0f), fminf(accum[idx].z * invFrames, 1.0f) }; /* prep :65-75 */
+    if (vignette > 0) { /* vignetting :18-32; length/smoothstep/mix as in ROCm's OpenCL library */
+        int x = idx % W, y = idx / W;
+        float px = (float)x / (float)W - 0.5f, py = (float)y / (float)H - 0.5f;
+        float d = fmaf(py, py, px * px);
+        float len = d < FLT_MIN ? sqrtf(fmaf(py * 0x1p+86f, py * 0x1p+86f, (px * 0x1p+86f) * (px * 0x1p+86f))) * 0x1p-86f : sqrtf(d);
+        float t = fminf(fmaxf(len, 0.0f), 1.0f);
+        float vig = 1 - (t * t) * fmaf(t, -2.0f, 3.0f);
+        for (int k = 0; k < 3; k++) c[k] = fmaf(c[k] * vig - c[k], vignette, c[k]);
+    }
+    if (gamma != 1.0f) for (int k = 0; k < 3; k++) c[k] = powf(c[k], gamma); /* gammaCorr :34-40 */
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2];
+}
+void orc_postproc(const RtFloat4* accum, int32_t W, int32_t H, int32_t frames, float vignette, float gamma, float chromatic,
+                  RtFloat4* outF, uint8_t* outRGBA8)
+{
+    float inv = 1 / (float)frames;
+    for (int idx = 0; idx < W * H; idx++) {
+        float c[3], p[3];
+        post_chain(accum, idx, W, H, inv, vignette, gamma, c);
+        if (chromatic > 0 && idx % W != 0) { /* chromatic :42-63 */
+            post_chain(accum, idx - 1, W, H, inv, vignette, gamma, p);
+            float o = chromatic;
+            c[1] = c[1] * (1 - o) + p[1] * o;
+            c[2] = c[2] * (1 - 2 * o) + p[2] * 2 * o;
+        }
+        float r = fminf(c[0], 1.0f), g = fminf(c[1], 1.0f), b = fminf(c[2], 1.0f); /* saveImage :77-86 */
+        if (outF) outF[idx] = v4(r, g, b, 1.0f);
+        if (outRGBA8) { outRGBA8[4 * idx] = (uint8_t)(r * 255); outRGBA8[4 * idx + 1] = (uint8_t)(g * 255); outRGBA8[4 * idx + 2] = (uint8_t)(b * 255); outRGBA8[4 * idx + 3] = 255; }
+    }
+}
+
 /* ---------------------------------------------------------------- unit hooks for the known-answer tests */
 void orc_test_random_float3(uint32_t* seed, float out[4]) { f4 r = rnd_float3(seed); out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w; }
 void orc_test_cosine_hemisphere(const float N[4], uint32_t* seed, float out[4])

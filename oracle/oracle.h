@@ -97,6 +97,10 @@ void orc_render_bands(const OrcScene* sc, const OrcConfig* cfg, const RtCamera* 
 void orc_trace_normals(const OrcScene* sc, const OrcConfig* cfg, const RtCamera* cam,
                        int32_t threads, RtFloat4* out);
 
+/* Renderer::PostProc + SaveFrame (renderer.cpp:95-124,303-308; src/cl/postproc.cl:7-86). */
+void orc_postproc(const RtFloat4* accum, int32_t W, int32_t H, int32_t frames, float vignette, float gamma, float chromatic,
+                  RtFloat4* outF, uint8_t* outRGBA8);
+
 /* Unit hooks for the known-answer tests. */
 void     orc_test_random_float3(uint32_t* seed, float out[4]);
 void     orc_test_cosine_hemisphere(const float N[4], uint32_t* seed, float out[4]);

@@ -46,6 +46,7 @@ def lib():
         L.orc_render_frame.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
         L.orc_render_bands.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
         L.orc_trace_normals.argtypes = [vp, vp, vp, i32, vp]
+        L.orc_postproc.argtypes = [vp, i32, i32, i32, C.c_float, C.c_float, C.c_float, vp, vp]
         _lib = L
     return _lib
 
@@ -58,6 +59,15 @@ def seed_stream(first, n):
     s = np.zeros(n, dtype=np.uint32)
     lib().orc_seed_stream(_p(s), first, n)
     return s
+
+
+def postproc(accum, frames, vignette=0.0, gamma=0.9, chromatic=0.0):
+    a = np.ascontiguousarray(accum, dtype=np.float32)
+    H, W = a.shape[:2]
+    f = np.zeros((H, W, 4), np.float32)
+    b = np.zeros((H, W, 4), np.uint8)
+    lib().orc_postproc(_p(a), W, H, int(frames), float(vignette), float(gamma), float(chromatic), _p(f), _p(b))
+    return f, b
 
 
 class Oracle:

@@ -44,6 +44,7 @@ def test_stage_by_stage_bit_exact(scene):
     n = Wd * Hd
     seeds = seed_stream(0, n)
     d.set_seeds(seeds.copy())
+    d.enable_steps()
     acc = np.zeros((Hd * Wd, 4), np.float32)
     d.reset()
     d.stage_begin_frame()
@@ -322,3 +323,36 @@ def test_full_size_properties_1080p():
     assert_bits(d3.read_accum(), ref, "1080p band vs oracle")
     for x in (d, d2, d3):
         x.close()
+
+
+def test_postproc_chain_matches_oracle():
+    from oracle.oracle_py import postproc
+    Wd, Hd = 160, 90
+    sa, cam, o, d = _pair(scenes.cube_scene, Wd, Hd, DEFAULT)
+    d.seed_default()
+    d.render(cam, 3)
+    acc = d.read_accum()
+    # no gamma: only + - * / sqrt fma -> bit-exact, float image and bytes
+    for vig, chroma in ((0.0, 0.0), (0.7, 0.0), (0.0, 0.15), (0.5, 0.05)):
+        f, b = d.postproc(3, vignette=vig, gamma=1.0, chromatic=chroma)
+        ef, eb = postproc(acc, 3, vig, 1.0, chroma)
+        assert_bits(f, ef, f"postproc float vig={vig} chroma={chroma}")
+        assert np.array_equal(b, eb)
+    # default gamma 0.9 goes through pow(): tolerance on floats, bytes may differ by one code
+    f, b = d.postproc(3, vignette=0.3, gamma=0.9, chromatic=0.05)
+    ef, eb = postproc(acc, 3, 0.3, 0.9, 0.05)
+    assert np.abs(f - ef).max() < 1e-5 and np.abs(b.astype(int) - eb.astype(int)).max() <= 1
+    d.close()
+
+
+def test_renderer_save_frame_png(tmp_path):
+    s, view = scenes.cube_scene()
+    r = Renderer(s, 64, 36)
+    r.SetCamera(view["origin"], view["forward"], fov=view["fov"], aperture=view["aperture"])
+    r.Init()
+    r.Tick(2)
+    p = tmp_path / "frame.png"
+    r.SaveFrame(p)
+    raw = p.read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n" and len(raw) > 64 * 36 * 3
+    r.close()

@@ -50,6 +50,7 @@ def stage_compare(name, scene_fn, Wd, Hd, variant, bounces=3):
     n = Wd * Hd
     seeds_o = seed_stream(0, n)
     d.set_seeds(seeds_o.copy())
+    d.enable_steps()
     acc_o = np.zeros((Hd, Wd, 4), np.float32)
     d.reset()
     d.stage_begin_frame()
