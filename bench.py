@@ -135,10 +135,12 @@ def main():
                        "shard": args.shard, "triangles": int(len(sa.prims)), "extend_variant": args.extend_variant},
             "traced_mrays_per_s": round(traced * (world if args.shard == "samples" else 1) / dt / 1e6, 2),
             "rays_per_step": {"extend": ctr["extend_rays"] // args.steps, "connect": ctr["connect_rays"] // args.steps},
-            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": round(ext_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "extend (k_trace_persist<false>)", "achieved": round(ext_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ext_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(ext_bytes), "avg_launch_ms": round(ext_ms, 5),
                          "launches": st["extend_launches"],
+                         "note": "achieved = algorithmic bytes (SURVEY 8(d) formula x device counters) / HIP-event time; node and triangle data "
+                                 "(~30 MB) are served from L1/L2/Infinity Cache, so achieved may exceed the HBM peak while `traffic` (PMC, DRAM side) stays far below it",
                          "per_ray": {"node_visits": round(ctr["extend_node_visits"] / max(ctr["extend_rays"], 1), 2),
                                      "prim_tests": round(ctr["extend_prim_tests"] / max(ctr["extend_rays"], 1), 2)}},
             "connect_roofline": {"achieved": round(con_gbs, 2), "frac": round(con_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(con_ms, 5)},
@@ -154,25 +156,12 @@ def main():
 
 
 def _seed_stream(out, first):
-    """seeds[i] = (first+i+1)-th xorshift32 output from 0x12345678 (reference renderer.cpp:195-196), vectorised:
-    the generator is linear over GF(2), so a jump is a 32x32 bit-matrix power; here a plain loop in C would do,
-    but the product library already owns one: reuse rt_seed_default's stream via numpy for offset 0 only."""
-    x = np.uint32(0x12345678)
-    # sequential in chunks with numpy scalar ops is slow for 2M+; use the device library's host loop through ctypes
+    """seeds[i] = (first+i+1)-th xorshift32 output from 0x12345678 (reference renderer.cpp:195-196), computed by the
+    host library's C loop (rth_seed_stream)."""
     import ctypes as C
     from magr_ray_tracer_amd import _lib
-    lib = _lib.host_lib()
-    if hasattr(lib, "rth_seed_stream"):
-        lib.rth_seed_stream.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
-        lib.rth_seed_stream(out.ctypes.data_as(C.c_void_p), int(first), int(out.size))
-        return
-    s = int(x)
-    M = 0xFFFFFFFF
-    for _ in range(first):
-        s ^= (s << 13) & M; s ^= s >> 17; s ^= (s << 5) & M
-    for i in range(out.size):
-        s ^= (s << 13) & M; s ^= s >> 17; s ^= (s << 5) & M
-        out[i] = s
+    if _lib.host_lib().rth_seed_stream(out.ctypes.data_as(C.c_void_p), int(first), int(out.size)) != 0:
+        raise RuntimeError("rth_seed_stream failed")
 
 
 def cpu_baseline(sa, cam, W, H, accel):

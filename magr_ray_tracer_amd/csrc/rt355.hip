@@ -260,14 +260,16 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         if (lr == 0) { if (tlas[i].BLASidx >= (uint32_t)nBlas) return fail(RT_E_INVALID, "tlas node %d: BLASidx out of range", i); }
         else if ((lr & 0xffffu) >= (uint32_t)nTlas || (lr >> 16) >= (uint32_t)nTlas) return fail(RT_E_INVALID, "tlas node %d: child out of range", i);
     }
-    const int stackCap = ctx->cfg.accel == RT_ACCEL_BVH4 ? RT_BVH4_STACK : RT_BVH2_STACK;
+    // The reference kernels give BVH2 32 and BVH4 64 stack entries (bvh.cl:15,57) and overflow silently beyond that
+    // (SBVH trees at alpha = 0 do get deeper than 32); this library sizes the LDS stack to the tree, up to 64 entries.
+    const int stackCap = RT_BVH4_STACK;
     int stackNeed = 1;
     for (int32_t b = 0; b < nBlas; b++) {
         if (blas[b].bvhIdx >= (uint32_t)nNodes) return fail(RT_E_INVALID, "instance %d: bvhIdx out of range", b);
         int need = ctx->cfg.accel == RT_ACCEL_BVH4 ? bvh4_stack_need((const RtBVHNode4*)bvhNodes, nNodes, blas[b].bvhIdx)
                                                    : bvh2_depth((const RtBVHNode2*)bvhNodes, nNodes, blas[b].bvhIdx);
         if (need < 0) return fail(RT_E_INVALID, "instance %d: malformed BVH (child index out of range or cycle)", b);
-        if (need > stackCap) return fail(RT_E_UNSUPPORTED, "instance %d: traversal needs %d stack entries, the reference kernels provide %d", b, need, stackCap);
+        if (need > stackCap) return fail(RT_E_UNSUPPORTED, "instance %d: traversal needs %d stack entries, at most %d are supported", b, need, stackCap);
         stackNeed = std::max(stackNeed, need);
     }
     ctx->stackEntries = std::min(stackCap, std::max(stackNeed + 1, 6)); // >= 6: flush_counters reuses 20 words of it

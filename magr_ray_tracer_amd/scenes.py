@@ -211,6 +211,39 @@ def two_blas_scene(alpha=0.0, n=24):
     return s, view
 
 
+def config5_scene(alpha=0.0, decimate=1):
+    """BASELINE config 5: robo-orb (35,600 tris) + terrarium_bot (40,012 tris), each its own BLAS under a TLAS, SBVH
+    alpha (0 = full spatial splits), glass on the terrarium dome.  Geometry: magr_ray_tracer_amd/assets/*.npz (converted
+    from the glTF files that ship with the reference; CC-BY-4.0, see assets/ATTRIBUTION.md)."""
+    import os
+    from . import gltf
+    adir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+    s = Scene()
+    _std_materials(s)
+
+    def place(name, height, at, matmap, default):
+        V, I, M, names = gltf.load_packed(os.path.join(adir, name))
+        V = V.astype(np.float64)
+        lo, hi = V.min(0), V.max(0)
+        sc = height / (hi[1] - lo[1])
+        V = (V - np.array([(lo[0] + hi[0]) / 2, lo[1], (lo[2] + hi[2]) / 2])) * sc + np.array(at)
+        V = V.astype(np.float32)
+        for mi, mn in enumerate(names):
+            tri = I[M == mi][::decimate]
+            if len(tri):
+                s.AddTriangles(V[tri], matmap.get(mn, default))
+
+    place("robo_orb.npz", 1.9, (-1.5, 0.0, 0.0), {"Coat": "mirror", "Coat_2": "mirror", "Butt": "red", "material": "green"}, "white")
+    s.AddQuad((-9, 0, -9), (-9, 0, 9), (9, 0, 9), (9, 0, -9), "grey")
+    s.AddQuad((-1.5, 5.5, -1.5), (1.5, 5.5, -1.5), (1.5, 5.5, 1.5), (-1.5, 5.5, 1.5), "white-light")
+    s.BuildBLAS(0, alpha)
+    start = s.num_prims
+    place("terrarium_bot.npz", 2.4, (1.7, 0.0, 0.0), {"glass": "white-glass", "ground": "sand", "inside": "sand", "pipes": "red"}, "white")
+    s.BuildBLAS(start, alpha)
+    view = dict(origin=(0.3, 2.3, 5.4), forward=(0.03, 0.2, 0.98), fov=62.0, aperture=0.02)
+    return s, view
+
+
 def camera_for(view, width, height, focalLength=1.0):
     return make_camera(width, height, view["origin"], view["forward"], fov=view.get("fov", 110.0),
                        aperture=view.get("aperture", 0.1), focalLength=focalLength)

@@ -297,7 +297,7 @@ static inline float isect_aabb(const RtRay* ray, f4 bmin, f4 bmax) /* bvh.cl:3-1
 static int traverse_bvh2(RtRay* ray, const OrcScene* sc, uint32_t root, int occlusion, OrcCounters* c) /* bvh.cl:13-54 */
 {
     const RtBVHNode2* nodes = sc->bvh2;
-    const RtBVHNode2* stack[RT_BVH2_STACK];
+    const RtBVHNode2* stack[RT_BVH4_STACK]; /* reference: 32 (bvh.cl:15); 64 here so that deep SBVH trees cannot overflow */
     const RtBVHNode2* node = nodes + root;
     uint32_t sp = 0; int steps = 0;
     float t_light = ray->t;

@@ -356,3 +356,40 @@ def test_renderer_save_frame_png(tmp_path):
     raw = p.read_bytes()
     assert raw[:8] == b"\x89PNG\r\n\x1a\n" and len(raw) > 64 * 36 * 3
     r.close()
+
+
+def test_config2_bunny_class_720p_kajiya():
+    """BASELINE config 2: ~70k-triangle closed mesh, binary SAH BVH, 1280x720, SHADING_SIMPLE ("Kajiya") — full frame vs oracle."""
+    Wd, Hd, frames = 1280, 720, 2
+    v = dict(DEFAULT, shading=0)
+    sa, cam, o, d = _pair(lambda: scenes.bunny_class(187), Wd, Hd, v)
+    assert 69000 < len(sa.prims) < 71000
+    cam["focalLength"] = o.focus(Wd // 2, Hd // 2, cam)
+    assert d.focus(Wd // 2, Hd // 2, cam) == cam["focalLength"]
+    acc, seeds, e, c = o.render(cam, frames, threads=1)
+    d.seed_default()
+    d.render(cam, frames)
+    assert_bits(d.read_accum(), acc, "config 2 accumulator")
+    assert np.array_equal(d.get_seeds(), seeds)
+    _ctr_equal(d.counters(), e, c)
+    assert c["rays"] == 0                      # Kajiya: no shadow rays
+    d.close()
+
+
+def test_config5_robo_orb_terrarium_tlas_sbvh():
+    """BASELINE config 5 geometry (robo-orb + terrarium_bot, 2 BLAS + TLAS, SBVH alpha = 0, glass dome) at reduced size.
+    Glass reaches exp() (Beer) -> 1e-4 tolerance; counters must agree within the few rays that flip."""
+    Wd, Hd, frames = 256, 144, 2
+    sa, cam, o, d = _pair(lambda: scenes.config5_scene(0.0), Wd, Hd, DEFAULT)
+    assert len(sa.prims) == 35600 + 40012 + 4 and len(sa.primIdx) > len(sa.prims)
+    cam["focalLength"] = o.focus(Wd // 2, Hd // 2, cam)
+    acc, seeds, e, c = o.render(cam, frames)
+    d.seed_default()
+    d.render(cam, frames)
+    got = d.read_accum()
+    rel = np.abs(got - acc) / np.maximum(np.abs(acc), 1e-3)
+    assert (rel > 1e-4).mean() < 2e-3, f"{(rel > 1e-4).sum()} of {rel.size} beyond 1e-4"
+    dc = d.counters()
+    assert abs(dc["extend_node_visits"] - e["node_visits"]) <= 0.002 * e["node_visits"]
+    assert dc["extend_tlas_visits"] > 0
+    d.close()

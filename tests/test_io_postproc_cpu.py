@@ -115,3 +115,40 @@ def test_obj_loader_conventions(tmp_path):
     assert np.allclose(p["v2"][2][:3], [12, 0, 1])
     # reversed winding flips the geometric normal (0,0,1) -> (0,0,-1)
     assert np.allclose(p["N"][0][:3], [0, 0, -1])
+
+
+def test_gltf_reader_applies_node_transforms(tmp_path):
+    import json
+    from magr_ray_tracer_amd import gltf
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    idx = np.array([0, 1, 2], np.uint16)
+    blob = pos.tobytes() + idx.tobytes() + b"\x00\x00"
+    (tmp_path / "s.bin").write_bytes(blob)
+    g = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}],
+         "nodes": [{"children": [1], "translation": [10, 0, 0]}, {"mesh": 0, "scale": [2, 2, 2], "rotation": [0, 0, 0.70710678, 0.70710678]}],
+         "meshes": [{"name": "tri", "primitives": [{"attributes": {"POSITION": 0}, "indices": 1, "material": 0}]}],
+         "materials": [{"name": "glass"}], "buffers": [{"uri": "s.bin", "byteLength": len(blob)}],
+         "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 6}],
+         "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"},
+                       {"bufferView": 1, "componentType": 5123, "count": 3, "type": "SCALAR"}]}
+    (tmp_path / "s.gltf").write_text(json.dumps(g))
+    parts = gltf.load_gltf(str(tmp_path / "s.gltf"))
+    assert len(parts) == 1 and parts[0]["material"] == "glass"
+    # scale 2, rotate 90 deg about z, then translate x+10: (1,0,0) -> (10,2,0), (0,1,0) -> (8,0,0)
+    assert np.allclose(parts[0]["vertices"], [[10, 0, 0], [10, 2, 0], [8, 0, 0]], atol=1e-5)
+    gltf.pack(parts, str(tmp_path / "m.npz"), source="unit")
+    V, I, M, names = gltf.load_packed(str(tmp_path / "m.npz"))
+    assert V.shape == (3, 3) and I.tolist() == [[0, 1, 2]] and names == ["glass"]
+
+
+def test_config5_scene_two_blas_from_converted_assets():
+    s, view = scenes.config5_scene(alpha=1.0, decimate=8)      # plain SAH and 1/8 of the triangles: fast on CPU
+    sa = s.arrays()
+    assert len(sa.blas) == 2 and len(sa.tlas) == 4 and sa.tlas[0]["leftRight"] == (1 | (2 << 16))
+    assert sa.blas["bvhIdx"][1] > 0
+    glass = [i for i, m in enumerate(sa.mats) if m["isDielectric"]]
+    assert len(glass) == 1 and (sa.prims["matIdx"] == glass[0]).sum() > 100      # the terrarium dome
+    o = Oracle(sa, 64, 36, **DEFAULT)
+    cam = scenes.camera_for(view, 64, 36)
+    acc, _, e, c = o.render(cam, 1)
+    assert e["tlas_visits"] > 0 and e["inst_visits"] > e["rays"] and acc[..., :3].mean() > 0.01
