@@ -43,13 +43,17 @@ def main():
     ap.add_argument("--extend-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stage launches with HIP events")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (default); gloo only for rehearsals")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses GPU 0 (requires --backend gloo)")
     args = ap.parse_args()
 
     import torch
     from magr_ray_tracer_amd import dist as rdist, scenes
     from magr_ray_tracer_amd.renderer import Device
 
-    rank, world, local = rdist.init_process_group()
+    rank, world, local = rdist.init_process_group(args.backend if args.gpus > 1 else None, set_device=not args.same_device)
+    if args.same_device:
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
@@ -78,7 +82,7 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     # ---- warmup ------------------------------------------------------------------------------------------
     if args.warmup > 0:
@@ -99,8 +103,9 @@ def main():
     rdist.reduce_accumulator(accum)
     barrier()
     dt = time.perf_counter() - t0
+    checksum = float(accum[..., :3].sum().item())
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}" if args.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -145,7 +150,7 @@ def main():
                                      "prim_tests": round(ctr["extend_prim_tests"] / max(ctr["extend_rays"], 1), 2)}},
             "connect_roofline": {"achieved": round(con_gbs, 2), "frac": round(con_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(con_ms, 5)},
             "stage_ms_per_step": {k[:-3]: round(st[k] / args.steps, 4) for k in st if k.endswith("_ms")},
-            "host_build_s": round(build_s, 2),
+            "host_build_s": round(build_s, 2), "accum_rgb_sum": checksum,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sa, cam, W, H, accel)

@@ -455,7 +455,8 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
         ctx->cursorUsed[bounce] = true;
     }
     ev_begin(ctx, ST_EXTEND);
-    if (ctx->persist)
+    // bounce 0: primary rays are coherent and finish together, refilling buys nothing -> one ray per lane
+    if (ctx->persist && (bounce > 0 || ctx->cfg.extend_variant == 3))
         hipLaunchKernelGGL((k_trace_persist<false>), dim3(ctx->persistGrid), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4)
         hipLaunchKernelGGL((k_extend<RT_ACCEL_BVH4, 0>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);

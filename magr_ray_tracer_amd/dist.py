@@ -38,7 +38,7 @@ def plan(shard, width, height, rank, world):
     return dict(y0=y0, y1=y1, seed_first=first, seed_count=n)
 
 
-def init_process_group(backend=None):
+def init_process_group(backend=None, set_device=True):
     import torch
     import torch.distributed as dist
     rank, world, local = rank_world()
@@ -47,7 +47,7 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if backend == "nccl" and set_device:
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
@@ -57,5 +57,10 @@ def reduce_accumulator(tensor):
     """The single exchange step of a render: SUM of the per-rank float accumulators (in place)."""
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+        if tensor.is_cuda and dist.get_backend() == "gloo":   # rehearsal path: gloo reduces on the host
+            host = tensor.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            tensor.copy_(host)
+        else:
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
     return tensor
