@@ -131,11 +131,13 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     ctx->gridMax = (ctx->nPix * std::max(1, c.max_bounces) + kBlock - 1) / kBlock; // connect may cover max_bounces*nPix shadow rays
     ctx->gridMax = std::max(ctx->gridMax, 4096);                                    // and the persistent grid (<= 256 CUs x 8 blocks)
     ctx->var = DevVariant{ c.shading, c.sampling, c.accel, c.russian_roulette ? 1 : 0, c.filter_fireflies ? 1 : 0, c.max_bounces };
-    {   // k_shade's grid must be co-resident: half of what the occupancy query admits, at most 4 per CU
+    {   // k_shade's grid must be co-resident.  The occupancy query can over-report by one workgroup per CU for
+        // SGPR-heavy 256-thread kernels on this chip (MI355X_MICROARCH.md, residency), so launch one fewer per CU.
         hipDeviceProp_t prop; int perCU = 0;
         HIPCHK(hipGetDeviceProperties(&prop, c.device));
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<true>, kBlock, 0));
-        ctx->shadeGrid = prop.multiProcessorCount * std::max(1, std::min(4, perCU / 2));
+        if (c.shading == RT_SHADING_NEE) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<true>, kBlock, 0));
+        else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<false>, kBlock, 0));
+        ctx->shadeGrid = prop.multiProcessorCount * std::max(1, perCU - 1);
         if (const char* g = getenv("RT355_SHADE_PER_CU")) { int v = atoi(g); if (v > 0 && v <= std::max(1, perCU - 1)) ctx->shadeGrid = prop.multiProcessorCount * v; }
     }
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -146,7 +148,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     auto& bag = ctx->queueAllocs;
 #define QA(field, count) if (rc == RT_OK) rc = dalloc(bag, &q.field, count)
     const size_t nTiles = (n + kBlock - 1) / kBlock;
-    for (int k = 0; k < 2; k++) { QA(O[k], n); QA(D[k], n); QA(inten[k], n); QA(meta[k], n); QA(tile[k], nTiles + 2); }
+    for (int k = 0; k < 2; k++) { QA(O[k], n); QA(D[k], n); QA(inten[k], n); QA(meta[k], n); QA(tile[k], nTiles + 2); QA(super[k], nTiles / 64 + 2); }
     QA(hit, n);
     QA(sA, nS); QA(sB, nS); QA(sC, nS);
     QA(nRays, RT_MAX_BOUNCES + 2); QA(nShadow, RT_MAX_BOUNCES + 2); QA(cursor, 2 * (RT_MAX_BOUNCES + 2));
@@ -165,7 +167,10 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     (void)hipMemsetAsync(q.ctrExtend, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
     (void)hipMemsetAsync(q.ctrConnect, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
     (void)hipMemsetAsync(q.seeds, 0, sizeof(uint32_t) * n, ctx->stream);
-    for (int k = 0; k < 2; k++) (void)hipMemsetAsync(q.tile[k], 0, sizeof(unsigned long long) * (nTiles + 2), ctx->stream);
+    for (int k = 0; k < 2; k++) {
+        (void)hipMemsetAsync(q.tile[k], 0, sizeof(unsigned long long) * (nTiles + 2), ctx->stream);
+        (void)hipMemsetAsync(q.super[k], 0, sizeof(unsigned long long) * (nTiles / 64 + 2), ctx->stream);
+    }
     (void)hipMemsetAsync(q.hit, 0, sizeof(float4) * n, ctx->stream);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *out = ctx;
@@ -477,6 +482,7 @@ extern "C" int rt_stage_shade(RtCtx* ctx, int32_t bounce)
     if (ctx->shadeRun[bounce] || (bounce > 0 && !ctx->shadeRun[bounce - 1]) || (bounce == 0 && !ctx->generated)) {
         const size_t nTiles = ((size_t)ctx->nPix + kBlock - 1) / kBlock;
         HIPCHK(hipMemsetAsync(ctx->q.tile[bounce & 1], 0, sizeof(unsigned long long) * (nTiles + 2), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->q.super[bounce & 1], 0, sizeof(unsigned long long) * (nTiles / 64 + 2), ctx->stream));
     }
     ev_begin(ctx, ST_SHADE);
     const dim3 sg((unsigned)std::max(1, std::min(ctx->shadeGrid, (ctx->nPix + kBlock - 1) / kBlock)));

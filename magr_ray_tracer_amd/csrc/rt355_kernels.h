@@ -61,6 +61,7 @@ struct DevQueues {
     float4* sA; float4* sB; float4* sC;
     // single-pass scan state of k_shade, one set per bounce parity: [1 + t] = status of tile t
     unsigned long long* tile[2];
+    unsigned long long* super[2];   // [s] = status of super-tile s (64 consecutive tiles), same encoding
     int32_t* nRays;    // [RT_MAX_BOUNCES+2]  rays entering bounce b
     int32_t* nShadow;  // [RT_MAX_BOUNCES+2]  shadow rays of bounce b occupy [nShadow[b], nShadow[b+1])
     int32_t* cursor;   // [2*(RT_MAX_BOUNCES+2)] work-queue heads of the persistent kernels (extend: [b], connect: [9+b])
@@ -457,7 +458,7 @@ RT_FORCEINLINE void primary_ray(const RtCamera& cam, int x, int y, int W, int H,
 __global__ __launch_bounds__(kBlock) void k_generate(DevQueues q, RtCamera cam, int aa)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (threadIdx.x == 0) q.tile[0][1 + blockIdx.x] = 0ull;   // arm shade(0)'s scan
+    if (threadIdx.x == 0) { q.tile[0][1 + blockIdx.x] = 0ull; if ((blockIdx.x & 63) == 0) q.super[0][blockIdx.x >> 6] = 0ull; }   // arm shade(0)'s scan
     if (i >= q.nPix) return;
     const int idx = q.firstPixel + i;
     uint32_t seed = q.seeds[i];
@@ -756,7 +757,7 @@ RT_FORCEINLINE float4 firefly(int on, float4 c) // wavefront.cl:125-127,196-198
     return c;
 }
 
-struct ShadowOut { float4 a, b, c; bool valid; };
+struct ShadowOut { float4* a; float4* b; float4* c; bool valid; };   // a/b/c: this lane's LDS slots (stored as soon as known)
 
 // neeShading (shading.cl:72-169) and kajiyaShading (:7-70) in one body; NEE selects the
 // light-sampling block and the lastSpecular rules.
@@ -801,9 +802,9 @@ RT_FORCEINLINE float4 shade_hit(const DevScene& sc, const DevVariant& var, SRay&
                 float4 Ld = muls(mul4(muls(lightColor, solidAngle), BRDF), dotNL);
                 float4 color = firefly(var.fireflies, mul4(Ld, sInt));
                 float4 so = add4(ray.I, muls(L, kEps));
-                sh.a = mk4(so.x, so.y, so.z, dist - 2 * kEps);
-                sh.b = mk4(L.x, L.y, L.z, __int_as_float(ray.pixel));
-                sh.c = color;
+                *sh.a = mk4(so.x, so.y, so.z, dist - 2 * kEps);
+                *sh.b = mk4(L.x, L.y, L.z, __int_as_float(ray.pixel));
+                *sh.c = color;
                 sh.valid = true;
             }
         }
@@ -840,11 +841,16 @@ RT_FORCEINLINE uint32_t tile_sh(unsigned long long v) { return (uint32_t)(v & 0x
 // G <= 4 per CU, half of what this kernel's registers/LDS admit, and uses no ticket atomics (8,100 tickets on
 // one word cost ~90 us per launch on this chip, more than the shading itself).
 template <bool NEE>
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevQueues q, DevVariant var, int bounce)
+__global__ __launch_bounds__(kBlock, 5) void k_shade(DevScene sc, DevQueues q, DevVariant var, int bounce)
 {
     __shared__ uint32_t sWaveE[kBlock / 64], sWaveS[kBlock / 64], sBaseE, sBaseS;
+    // Survivors wait in LDS (104 B per lane) while the ordered scan resolves, instead of in ~28 registers: the
+    // kernel's occupancy is set by the shading code, not by values that are merely parked across the scan.
+    __shared__ float4 sExtO[kBlock], sExtD[kBlock], sExtI[kBlock], sShA[kBlock], sShB[kBlock], sShC[kBlock];
+    __shared__ uint2 sExtM[kBlock];
     const int cur = bounce & 1, nxt = cur ^ 1;
     unsigned long long* state = q.tile[cur];
+    unsigned long long* const* super = q.super;
     const int n = q.nRays[bounce];
     if (n <= 0) { // empty queue: still publish the (empty) next queue
         if (blockIdx.x == 0 && threadIdx.x == 0) { q.nRays[bounce + 1] = 0; q.nShadow[bounce + 1] = q.nShadow[bounce]; }
@@ -858,10 +864,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevQueues q, DevV
         const int i = (int)tile * kBlock + threadIdx.x;
         if (threadIdx.x == 0) q.tile[nxt][1 + tile] = 0ull;     // arm shade(bounce+1)'s scan (its queue is never longer)
 
-        ExtRay ext; ext.valid = false;
-        ShadowOut sh; sh.valid = false;
-        int pixel = 0;
+        bool extValid = false, shValid = false;
         if (i < n) {
+            ExtRay ext; ext.valid = false;
+            ShadowOut sh; sh.valid = false; sh.a = &sShA[threadIdx.x]; sh.b = &sShB[threadIdx.x]; sh.c = &sShC[threadIdx.x];
             const float4 hit = q.hit[i];
             const uint2 meta = q.meta[cur][i];
             SRay ray;
@@ -869,7 +875,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevQueues q, DevV
             ray.t = hit.x; ray.prim = __float_as_int(hit.y); ray.u = hit.z; ray.v = hit.w;
             ray.pixel = (int)meta.x; ray.bounces = (int)(meta.y & kMetaBounceMask);
             ray.inside = (meta.y & kMetaInside) != 0; ray.lastSpec = (meta.y & kMetaLastSpec) != 0;
-            pixel = ray.pixel;
             if (ray.prim == -1) { // wavefront.cl:109-112, sky = skydome.cl:7
                 float4 c = mul4(ray.inten, mk4(0.0784f, 0.0941f, 0.3215f, 0.0f));
                 q.accum[ray.pixel] = add4(q.accum[ray.pixel], c);
@@ -885,56 +890,94 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene sc, DevQueues q, DevV
                 // one path per pixel and launch: the add is race-free; adding an exact zero is skipped
                 if (color.x != 0.0f || color.y != 0.0f || color.z != 0.0f || color.w != 0.0f)
                     q.accum[ray.pixel] = add4(q.accum[ray.pixel], color);
-                if (!(ext.valid && ext.bounces <= RT_MAX_BOUNCES)) ext.valid = false;   // wavefront.cl:129
+                if (ext.valid && ext.bounces <= RT_MAX_BOUNCES) {   // wavefront.cl:129
+                    extValid = true;
+                    sExtO[threadIdx.x] = ext.O; sExtD[threadIdx.x] = ext.D; sExtI[threadIdx.x] = ext.inten;
+                    sExtM[threadIdx.x] = make_uint2((uint32_t)ray.pixel, (uint32_t)ext.bounces | (ext.inside ? kMetaInside : 0u) | (ext.lastSpec ? kMetaLastSpec : 0u));
+                }
+                shValid = sh.valid;
             }
         }
         // wave votes + ordered scan across tiles (replaces atomic_inc on numOutRays / shadowRays, wavefront.cl:131,136)
-        const unsigned long long em = __ballot(ext.valid), sm = __ballot(sh.valid);
+        const unsigned long long em = __ballot(extValid), sm = __ballot(shValid);
         if (lane == 0) { sWaveE[wave] = (uint32_t)__popcll(em); sWaveS[wave] = (uint32_t)__popcll(sm); }
         __syncthreads();
         if (wave == 0) {
             uint32_t aggE = 0, aggS = 0;
 #pragma unroll
             for (int w = 0; w < kBlock / 64; w++) { aggE += sWaveE[w]; aggS += sWaveS[w]; }
-            uint32_t preE = 0, preS = 0;
-            if (tile > 0) {
-                if (lane == 0) __hip_atomic_store(&state[1 + tile], tile_pack(kTileAgg, aggE, aggS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int top = (int)tile - 1;                 // look back 64 predecessors per step
-                for (;;) {
-                    const int t = top - lane;
-                    unsigned long long v = kTilePrefix;  // lanes before tile 0 read as "prefix 0"
-                    if (t >= 0) {
-                        v = __hip_atomic_load(&state[1 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        while ((v >> 62) == 0ull) { __builtin_amdgcn_s_sleep(2); v = __hip_atomic_load(&state[1 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                    }
-                    const unsigned long long isPre = __ballot((v >> 62) == 2ull);
-                    const int stop = isPre ? __ffsll((long long)isPre) - 1 : 64;   // nearest predecessor with an inclusive prefix
-                    uint32_t e = lane <= stop ? tile_ext(v) : 0u, s2 = lane <= stop ? tile_sh(v) : 0u;
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) { e += __shfl_xor(e, off, 64); s2 += __shfl_xor(s2, off, 64); }
-                    preE += e; preS += s2;
-                    if (isPre) break;
-                    top -= 64;
+            // Two-level ordered scan.  Level 1: tiles publish their counts; a tile sums the counts of the earlier tiles of
+            // its own super-tile (64 tiles, one 64-lane read).  Level 2: the last tile of a super-tile publishes the
+            // super-tile total and resolves its inclusive prefix by decoupled look-back over the (<= a few hundred)
+            // super-tile words; every tile then adds the inclusive prefix of the previous super-tile.  All waits are on
+            // smaller tile ids (see the kernel comment).  Flag and payload share one 8-byte word (agent-scope atomics).
+            const uint32_t sup = tile >> 6, inSup = tile & 63u;
+            if (lane == 0) {
+                __hip_atomic_store(&state[1 + tile], tile_pack(kTileAgg, aggE, aggS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (inSup == 0) super[nxt][sup] = 0ull;           // arm shade(bounce+1)'s level 2
+            }
+            uint32_t inE = 0, inS = 0;                            // counts of tiles [64*sup, tile)
+            {
+                unsigned long long v = 0ull;
+                if ((uint32_t)lane < inSup) {
+                    const uint32_t t = (sup << 6) + (uint32_t)lane;
+                    v = __hip_atomic_load(&state[1 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while ((v >> 62) == 0ull) { __builtin_amdgcn_s_sleep(1); v = __hip_atomic_load(&state[1 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                 }
+                inE = tile_ext(v); inS = tile_sh(v);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { inE += __shfl_xor(inE, off, 64); inS += __shfl_xor(inS, off, 64); }
+            }
+            uint32_t preE = 0, preS = 0;                          // inclusive prefix of super-tiles [0, sup)
+            if (inSup == 63u) {
+                // this tile closes its super-tile: publish the total, then look back over the super-tile words
+                const uint32_t totE = inE + aggE, totS = inS + aggS;
+                if (sup > 0) {
+                    if (lane == 0) __hip_atomic_store(&super[cur][sup], tile_pack(kTileAgg, totE, totS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int top = (int)sup - 1;
+                    for (;;) {
+                        const int t = top - lane;
+                        unsigned long long v = kTilePrefix;
+                        if (t >= 0) {
+                            v = __hip_atomic_load(&super[cur][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            while ((v >> 62) == 0ull) { __builtin_amdgcn_s_sleep(1); v = __hip_atomic_load(&super[cur][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        }
+                        const unsigned long long isPre = __ballot((v >> 62) == 2ull);
+                        const int stop = isPre ? __ffsll((long long)isPre) - 1 : 64;
+                        uint32_t e = lane <= stop ? tile_ext(v) : 0u, s2 = lane <= stop ? tile_sh(v) : 0u;
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) { e += __shfl_xor(e, off, 64); s2 += __shfl_xor(s2, off, 64); }
+                        preE += e; preS += s2;
+                        if (isPre) break;
+                        top -= 64;
+                    }
+                }
+                if (lane == 0) __hip_atomic_store(&super[cur][sup], tile_pack(kTilePrefix, preE + totE, preS + totS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (sup > 0) {
+                unsigned long long v = 0ull;
+                if (lane == 0) {
+                    v = __hip_atomic_load(&super[cur][sup - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while ((v >> 62) != 2ull) { __builtin_amdgcn_s_sleep(1); v = __hip_atomic_load(&super[cur][sup - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                }
+                preE = tile_ext(v); preS = tile_sh(v);            // lane 0 holds it; only lane 0 uses it below
             }
             if (lane == 0) {
-                __hip_atomic_store(&state[1 + tile], tile_pack(kTilePrefix, preE + aggE, preS + aggS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sBaseE = preE; sBaseS = preS;
-                if (tile == numTiles - 1) { q.nRays[bounce + 1] = (int)(preE + aggE); q.nShadow[bounce + 1] = shadowBase + (int)(preS + aggS); }
+                sBaseE = preE + inE; sBaseS = preS + inS;
+                if (tile == numTiles - 1) { q.nRays[bounce + 1] = (int)(preE + inE + aggE); q.nShadow[bounce + 1] = shadowBase + (int)(preS + inS + aggS); }
             }
         }
         __syncthreads();
         uint32_t baseE = sBaseE, baseS = sBaseS + (uint32_t)shadowBase;
         for (int w = 0; w < wave; w++) { baseE += sWaveE[w]; baseS += sWaveS[w]; }
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (ext.valid) {
+        if (extValid) {
             const uint32_t dst = baseE + (uint32_t)__popcll(em & below);
-            q.O[nxt][dst] = ext.O; q.D[nxt][dst] = ext.D; q.inten[nxt][dst] = ext.inten;
-            q.meta[nxt][dst] = make_uint2((uint32_t)pixel, (uint32_t)ext.bounces | (ext.inside ? kMetaInside : 0u) | (ext.lastSpec ? kMetaLastSpec : 0u));
+            q.O[nxt][dst] = sExtO[threadIdx.x]; q.D[nxt][dst] = sExtD[threadIdx.x]; q.inten[nxt][dst] = sExtI[threadIdx.x];
+            q.meta[nxt][dst] = sExtM[threadIdx.x];
         }
-        if (sh.valid) {
+        if (shValid) {
             const uint32_t dst = baseS + (uint32_t)__popcll(sm & below);
-            q.sA[dst] = sh.a; q.sB[dst] = sh.b; q.sC[dst] = sh.c;
+            q.sA[dst] = sShA[threadIdx.x]; q.sB[dst] = sShB[threadIdx.x]; q.sC[dst] = sShC[threadIdx.x];
         }
         __syncthreads();   // LDS words are reused by the next tile
     }
