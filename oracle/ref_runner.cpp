@@ -41,4 +41,20 @@ int ref_launch(void* module, const char* kernel, unsigned global, unsigned local
     CHK(hipDeviceSynchronize());
     return 0;
 }
+// same, bracketed by HIP events: *ms = kernel time (used to time the reference's own extend on the MI355X)
+int ref_launch_timed(void* module, const char* kernel, unsigned global, unsigned local, void** args, float* ms)
+{
+    hipFunction_t f;
+    CHK(hipModuleGetFunction(&f, (hipModule_t)module, kernel));
+    if (local == 0 || global % local) { g_err = "global size must be a multiple of local size"; return -1; }
+    hipEvent_t a, b;
+    CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+    CHK(hipEventRecord(a, nullptr));
+    CHK(hipModuleLaunchKernel(f, global / local, 1, 1, local, 1, 1, 0, nullptr, args, nullptr));
+    CHK(hipEventRecord(b, nullptr));
+    CHK(hipEventSynchronize(b));
+    CHK(hipEventElapsedTime(ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return 0;
+}
 }

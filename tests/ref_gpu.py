@@ -75,6 +75,23 @@ class RefGPU:
                                          for h in hold])
         self._chk(self.R.ref_launch(self.mod, name.encode(), g, l, arr))
 
+    def launch_timed(self, name, g, l, args):
+        hold = [a if isinstance(a, np.ndarray) else C.c_void_p(a.value) for a in args]
+        arr = (C.c_void_p * len(args))(*[h.ctypes.data_as(C.c_void_p) if isinstance(h, np.ndarray) else C.cast(C.pointer(h), C.c_void_p)
+                                         for h in hold])
+        ms = C.c_float(0)
+        self._chk(self.R.ref_launch_timed(self.mod, name.encode(), g, l, arr, C.byref(ms)))
+        return ms.value
+
+    def extend_timed(self, rays, global_size, local_size=256):
+        """The reference's extend with `global_size` persistent work-items (reference: 2560, constants.h:28-31).
+        Timing only: with more than one work-group the kernel's counter swap races (Appendix B #3), so numInRays is
+        pre-set and the result is not used for parity."""
+        n = len(rays)
+        d_rays = self.dbuf(rays)
+        self.set_counts(n, n, 0)
+        return self.launch_timed("extend", global_size, local_size, [d_rays, self.prims, self.tlas, self.blas, self.nodes, self.idx, self.accum, self.d_set])
+
     def set_counts(self, numIn=0, numOut=0, shadow=0):
         self.settings["numInRays"], self.settings["numOutRays"], self.settings["shadowRays"] = numIn, numOut, shadow
         self.h2d(self.d_set, self.settings)
