@@ -345,10 +345,43 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
             if (rc == RT_OK) ctx->layout = 1;
         }
     }
+    if (rc == RT_OK && ctx->cfg.accel == RT_ACCEL_BVH4 && ctx->cfg.extend_variant != 1 && nIdx < (1 << 24)) {
+        const RtBVHNode4* n4 = (const RtBVHNode4*)bvhNodes;
+        bool fits = true;
+        for (int32_t i = 0; i < nNodes && fits; i++) for (int k = 0; k < 4; k++) if (n4[i].first[k] != RT_INVALID && n4[i].count[k] > 127) fits = false;
+        if (fits) {
+            auto f2u = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+            std::vector<float4> quads((size_t)nNodes * 8, make_float4(0, 0, 0, 0));
+            for (int32_t i = 0; i < nNodes; i++) {
+                float b[24]; uint32_t e[4];
+                for (int k = 0; k < 4; k++) {
+                    const RtFloat4& mn = n4[i].aabbMin[k]; const RtFloat4& mx = n4[i].aabbMax[k];
+                    b[k * 6 + 0] = mn.x; b[k * 6 + 1] = mn.y; b[k * 6 + 2] = mn.z; b[k * 6 + 3] = mx.x; b[k * 6 + 4] = mx.y; b[k * 6 + 5] = mx.z;
+                    if (n4[i].first[k] == RT_INVALID) e[k] = 0xffffffffu;
+                    else if (n4[i].count[k] > 0) e[k] = 0x80000000u | ((uint32_t)n4[i].count[k] << 24) | (uint32_t)n4[i].first[k];
+                    else e[k] = (uint32_t)n4[i].first[k];
+                }
+                for (int v = 0; v < 6; v++) quads[(size_t)i * 8 + v] = make_float4(b[v * 4], b[v * 4 + 1], b[v * 4 + 2], b[v * 4 + 3]);
+                quads[(size_t)i * 8 + 6] = make_float4(f2u(e[0]), f2u(e[1]), f2u(e[2]), f2u(e[3]));
+            }
+            std::vector<float4> recs((size_t)nIdx * 3);
+            for (int32_t s = 0; s < nIdx; s++) {
+                const RtPrimitive& p = prims[primIdx[s]];
+                const RtTriangle& t = p.obj.triangle;
+                const bool plain = p.objType == RT_PRIM_TRIANGLE && t.v0.w == 0.0f && t.v1.w == 0.0f && t.v2.w == 0.0f;
+                recs[(size_t)s * 3 + 0] = make_float4(t.v0.x, t.v0.y, t.v0.z, t.v1.x);
+                recs[(size_t)s * 3 + 1] = make_float4(t.v1.y, t.v1.z, t.v2.x, t.v2.y);
+                recs[(size_t)s * 3 + 2] = make_float4(t.v2.z, f2u(primIdx[s]), f2u(plain ? 0u : 1u), 0);
+            }
+            rc = upload(ctx, &sc.quads, quads.data(), quads.size());
+            if (rc == RT_OK) rc = upload(ctx, &sc.triRecs, recs.data(), recs.size());
+            if (rc == RT_OK) ctx->layout = 1;
+        }
+    }
     if (rc != RT_OK) { free_bag(ctx->sceneAllocs); ctx->sceneLoaded = false; return rc; }
     sc.nLights = nLights; sc.nPrims = nPrims; sc.nBlas = nBlas;
     // persistent-wavefront traversal: layout 1 and a TLAS whose root is a leaf (one BLAS)
-    ctx->persist = ctx->layout == 1 && tlas[0].leftRight == 0 && ctx->cfg.extend_variant != 2;
+    ctx->persist = ctx->layout == 1 && ctx->cfg.accel == RT_ACCEL_BVH2 && tlas[0].leftRight == 0 && ctx->cfg.extend_variant != 2;
     if (ctx->persist) {
         int perCU = 0; hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->cfg.device));
@@ -463,6 +496,8 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
     // bounce 0: primary rays are coherent and finish together, refilling buys nothing -> one ray per lane
     if (ctx->persist && (bounce > 0 || ctx->cfg.extend_variant == 3))
         hipLaunchKernelGGL((k_trace_persist<false>), dim3(ctx->persistGrid), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+    else if (ctx->cfg.accel == RT_ACCEL_BVH4 && ctx->layout == 1)
+        hipLaunchKernelGGL((k_extend<RT_ACCEL_BVH4, 1>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4)
         hipLaunchKernelGGL((k_extend<RT_ACCEL_BVH4, 0>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
     else if (ctx->layout == 1)
@@ -508,6 +543,8 @@ extern "C" int rt_stage_connect(RtCtx* ctx, int32_t b0, int32_t b1)
     ev_begin(ctx, ST_CONNECT);
     if (ctx->persist)
         hipLaunchKernelGGL((k_trace_persist<true>), dim3(ctx->persistGrid), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1, 0, ctx->tune);
+    else if (ctx->cfg.accel == RT_ACCEL_BVH4 && ctx->layout == 1)
+        hipLaunchKernelGGL((k_connect<RT_ACCEL_BVH4, 1>), grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4)
         hipLaunchKernelGGL((k_connect<RT_ACCEL_BVH4, 0>), grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
     else if (ctx->layout == 1)

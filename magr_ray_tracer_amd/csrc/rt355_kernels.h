@@ -51,6 +51,7 @@ struct DevScene {
     const float4*        pairs;      // [nNodes][4]  both child boxes + encoded child entries of interior node i
     const float4*        triRecs;    // [nIdx][3]    leaf-ordered triangle vertices + primitive id
     const uint32_t*      rootEntry;  // [nBlas]      encoded root of every instance
+    const float4*        quads;      // [nNodes][8]  layout 1 of the BVH4: four child boxes + four encoded child entries (128 B)
     int32_t nLights, nPrims, nBlas;
 };
 struct DevQueues {
@@ -341,6 +342,48 @@ RT_FORCEINLINE int traverse_bvh4(const DevScene& sc, TRay& r, uint32_t root, uin
     return steps;
 }
 
+// Layout 1 of the BVH4 (derived at upload from the unchanged BVHNode4 array): quads[i] = 128 B,
+//   floats 0..23 = {min.xyz, max.xyz} of child slots 0..3, q6 = entry(slot 0..3) (0xffffffff = unused slot, else as
+//   for the BVH2 layout: interior node id, or leaf bit | count << 24 | first).  7 sixteen-byte loads from two 64-B lines
+// instead of 10 from three, and triangles come from the leaf-ordered triRecs.  Order of evaluation as bvh.cl:55-96.
+static constexpr uint32_t kNoChild = 0xffffffffu;
+template <bool OCC>
+RT_FORCEINLINE int traverse_bvh4_packed(const DevScene& sc, TRay& r, uint32_t root, uint32_t* stk, WorkCtr& wc)
+{
+    uint32_t node = root, sp = 0;
+    int steps = 0;
+    const float tLight = r.t;
+    for (;;) {
+        steps++; wc.node++;
+        const float4* p = sc.quads + (size_t)node * 8;
+        const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5], q6 = p[6];
+        const uint32_t e[4] = { __float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w) };
+        float dist[4];
+        dist[0] = e[0] != kNoChild ? slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f)) : kFar;
+        dist[1] = e[1] != kNoChild ? slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f)) : kFar;
+        dist[2] = e[2] != kNoChild ? slab(r, mk4(q3.x, q3.y, q3.z, 0.0f), mk4(q3.w, q4.x, q4.y, 0.0f)) : kFar;
+        dist[3] = e[3] != kNoChild ? slab(r, mk4(q4.z, q4.w, q5.x, 0.0f), mk4(q5.y, q5.z, q5.w, 0.0f)) : kFar;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (e[k] == kNoChild) continue;
+            if (dist[k] >= tLight) continue;
+            if (e[k] & kLeafBit) {
+                const uint32_t first = e[k] & 0x00ffffffu, count = (e[k] >> 24) & 0x7fu;
+                for (uint32_t j = 0; j < count; j++) {
+                    wc.prim++;
+                    test_tri_packed(sc, first + j, r);
+                    if (OCC && r.t < tLight) return -1;
+                }
+            } else {
+                STK(sp) = e[k]; sp++;
+            }
+        }
+        if (sp == 0) break;
+        node = STK(--sp);
+    }
+    return steps;
+}
+
 // instanceIntersect, tlas.cl:9-26 with transformRay :3-8 and util.cl:61-87.
 template <int ACCEL, int LAYOUT, bool OCC>
 RT_FORCEINLINE int traverse_instance(const DevScene& sc, TRay& r, const RtBVHInstance* inst, uint32_t instIdx, uint32_t* stk, WorkCtr& wc)
@@ -354,7 +397,7 @@ RT_FORCEINLINE int traverse_instance(const DevScene& sc, TRay& r, const RtBVHIns
     r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
     wc.inst++;
     int steps;
-    if (ACCEL == RT_ACCEL_BVH4) steps = traverse_bvh4<OCC>(sc, r, inst->bvhIdx, stk, wc);
+    if (ACCEL == RT_ACCEL_BVH4) steps = LAYOUT == 1 ? traverse_bvh4_packed<OCC>(sc, r, inst->bvhIdx, stk, wc) : traverse_bvh4<OCC>(sc, r, inst->bvhIdx, stk, wc);
     else if (LAYOUT == 1) steps = traverse_bvh2_packed<OCC>(sc, r, sc.rootEntry[instIdx], stk, wc);
     else steps = traverse_bvh2<OCC>(sc, r, inst->bvhIdx, stk, wc);
     r.ox = bx; r.oy = by; r.oz = bz; r.dx = bdx; r.dy = bdy; r.dz = bdz; r.rx = brx; r.ry = bry; r.rz = brz;
