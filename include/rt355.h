@@ -119,6 +119,9 @@ int rt_focus(RtCtx* ctx, int32_t x, int32_t y, const RtCamera* cam, float* t);
 
 /* accumBuffer->CopyFromDevice() (renderer.cpp:128): full frame float4[width*height]. */
 int rt_read_accum(RtCtx* ctx, RtFloat4* out);
+/* Checkpoint restore: overwrite the accumulator (the state carried across frames is {accum, seeds, settings->frames};
+ * the reference has no checkpointing — SURVEY.md §5). */
+int rt_write_accum(RtCtx* ctx, const RtFloat4* in);
 int rt_read_counters(RtCtx* ctx, RtCounters* out);
 int rt_reset_counters(RtCtx* ctx);
 int rt_read_stage_times(RtCtx* ctx, RtStageTimes* out);

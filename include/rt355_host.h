@@ -74,7 +74,12 @@ int  rth_renderer_set_camera(RthRenderer* r, const float origin[3], const float 
 int  rth_renderer_tick(RthRenderer* r, int frames);                       /* Renderer::Tick x frames */
 int  rth_renderer_read(RthRenderer* r, RtFloat4* out, float* energy);     /* accumBuffer read-back + ComputeEnergy */
 int  rth_renderer_camera(RthRenderer* r, RtCamera* out);
-int  rth_renderer_save_frame(RthRenderer* r, const char* file);          /* Renderer::SaveFrame (renderer.cpp:303-308) */
+int  rth_renderer_save_frame(RthRenderer* r, const char* file);
+/* CameraManager::Move / MouseMove / Zoom (camera.h:47-99); the next Tick() sees camera.moved and resets (renderer.cpp:41-46). */
+int  rth_renderer_camera_move(RthRenderer* r, int camdir /* 0 Forward 1 Backwards 2 Left 3 Right 4 Up 5 Down */);
+int  rth_renderer_camera_mouse(RthRenderer* r, float xOffset, float yOffset);
+int  rth_renderer_camera_zoom(RthRenderer* r, float offset);
+int  rth_renderer_frames(RthRenderer* r);                                 /* settings->frames */          /* Renderer::SaveFrame (renderer.cpp:303-308) */
 
 #ifdef __cplusplus
 }

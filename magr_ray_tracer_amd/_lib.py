@@ -59,7 +59,7 @@ MAX_BOUNCES = 7
 DEVICE_SYMBOLS = [
     "rt_last_error", "rt_device_count", "rt_create", "rt_destroy", "rt_upload_scene", "rt_set_seeds", "rt_seed_default",
     "rt_get_seeds", "rt_bind_accum", "rt_accum_device_ptr", "rt_stream", "rt_reset", "rt_render", "rt_synchronize", "rt_focus",
-    "rt_read_accum", "rt_postproc", "rt_read_counters", "rt_reset_counters", "rt_read_stage_times", "rt_reset_stage_times",
+    "rt_read_accum", "rt_write_accum", "rt_postproc", "rt_read_counters", "rt_reset_counters", "rt_read_stage_times", "rt_reset_stage_times",
     "rt_stage_begin_frame", "rt_stage_generate", "rt_stage_extend", "rt_stage_shade", "rt_stage_connect",
     "rt_debug_get_rays", "rt_debug_set_rays", "rt_debug_get_shadow", "rt_debug_enable_steps", "rt_debug_get_steps"]
 HOST_SYMBOLS = [
@@ -69,7 +69,7 @@ HOST_SYMBOLS = [
     "rth_bvh2_nodes", "rth_bvh4_nodes", "rth_prim_idx", "rth_tlas_nodes", "rth_blas_nodes", "rth_bvh_stats", "rth_camera",
     "rth_renderer_create", "rth_renderer_destroy", "rth_renderer_init", "rth_renderer_set_camera", "rth_renderer_tick",
     "rth_renderer_read", "rth_renderer_camera", "rth_seed_stream", "rth_load_model", "rth_save_png",
-    "rth_renderer_save_frame"]
+    "rth_renderer_save_frame", "rth_renderer_camera_move", "rth_renderer_camera_mouse", "rth_renderer_camera_zoom", "rth_renderer_frames"]
 
 _dev = None
 _host = None
@@ -112,6 +112,7 @@ def device_lib():
         lib.rt_focus.argtypes = [vp, i32, i32, vp, C.POINTER(C.c_float)]
         lib.rt_read_accum.argtypes = [vp, vp]
         lib.rt_read_counters.argtypes = [vp, vp]
+        lib.rt_write_accum.argtypes = [vp, vp]
         lib.rt_postproc.argtypes = [vp, i32, C.c_float, C.c_float, C.c_float, vp, vp]
         lib.rt_reset_counters.argtypes = [vp]
         lib.rt_read_stage_times.argtypes = [vp, vp]
@@ -169,6 +170,10 @@ def host_lib():
         lib.rth_load_model.argtypes = [vp, cp, cp, fp, i32]
         lib.rth_save_png.argtypes = [cp, i32, i32, vp]
         lib.rth_renderer_save_frame.argtypes = [vp, cp]
+        lib.rth_renderer_camera_move.argtypes = [vp, i32]
+        lib.rth_renderer_camera_mouse.argtypes = [vp, C.c_float, C.c_float]
+        lib.rth_renderer_camera_zoom.argtypes = [vp, C.c_float]
+        lib.rth_renderer_frames.argtypes = [vp]
         _host = lib
     return _host
 

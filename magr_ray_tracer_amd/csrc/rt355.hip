@@ -617,6 +617,16 @@ extern "C" int rt_read_accum(RtCtx* ctx, RtFloat4* out)
     HIPCHK(hipMemcpy(out, ctx->q.accum, sizeof(float4) * (size_t)ctx->cfg.width * ctx->cfg.height, hipMemcpyDeviceToHost));
     return RT_OK;
 }
+// Restore half of a checkpoint: the running-sum accumulator (SURVEY.md §5 "Checkpoint / resume": the state a render
+// carries across frames is {accum, seeds, frames}; seeds go through rt_set_seeds, frames live in the caller's Settings).
+extern "C" int rt_write_accum(RtCtx* ctx, const RtFloat4* in)
+{
+    if (!ctx || !in) return fail(RT_E_INVALID, "rt_write_accum: null argument");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(ctx->q.accum, in, sizeof(float4) * (size_t)ctx->cfg.width * ctx->cfg.height, hipMemcpyHostToDevice));
+    return RT_OK;
+}
 static int sum_table(RtCtx* ctx, const unsigned long long* dev, uint64_t out5[5])
 {
     std::vector<unsigned long long> h((size_t)ctx->gridMax * 5);

@@ -158,6 +158,11 @@ extern "C" int rth_save_png(const char* file, int w, int h, const RtFloat4* data
     if (!file || !data || w <= 0 || h <= 0) { g_herr = "rth_save_png: bad argument"; return -1; }
     GUARD(SavePNG(file, w, h, data))
 }
+// Renderer input half that touches the path (renderer.cpp:310-365): camera controller, then Tick() resets the accumulator
+extern "C" int rth_renderer_camera_move(RthRenderer* r, int camdir) { GUARD(r->r->camera.Move(camdir, 0.0f)) }
+extern "C" int rth_renderer_camera_mouse(RthRenderer* r, float dx, float dy) { GUARD(r->r->camera.MouseMove(dx, dy)) }
+extern "C" int rth_renderer_camera_zoom(RthRenderer* r, float offset) { GUARD(r->r->camera.Zoom(offset)) }
+extern "C" int rth_renderer_frames(RthRenderer* r) { return r && r->r->settings ? r->r->settings->frames : -1; }
 extern "C" int rth_renderer_save_frame(RthRenderer* r, const char* file) { GUARD(r->r->SaveFrame(file)) }
 
 // seeds[i] = (first+i+1)-th xorshift32 output from 0x12345678 — the reference's host seed loop

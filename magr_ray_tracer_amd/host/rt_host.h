@@ -156,6 +156,13 @@ public:
     bool  moved = true;
     void Fov(float vfov);
     void UpdateCamVec();
+    // controller (camera.h:47-99): dir 0..5 = Forward, Backwards, Left, Right, Up, Down
+    void Move(int camdir, float deltaTime);
+    void MouseMove(float xOffset, float yOffset);
+    void Zoom(float offset);
+    float mouseSensivity = 0.5f, speed = 1.f;
+private:
+    float yaw_ = 0, pitch_ = 0;   // uninitialised in the reference (camera.h:20-21); zero here
 };
 
 // reference: src/renderer.h:23-26,36 (ImGuiData kernel variants)

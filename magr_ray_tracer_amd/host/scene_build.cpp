@@ -103,6 +103,33 @@ void CameraManager::Fov(float vfov) // camera.h:101-109 (theta is a double there
     viewportHeight = (float)(2 * h);
     viewportWidth = aspect * viewportHeight;
 }
+void CameraManager::Move(int camdir, float) // camera.h:47-73 (velocity = speed, deltaTime unused there too)
+{
+    moved = true;
+    const float v = speed;
+    auto axpy = [&](const RtFloat4& d, float s) { cam.origin.x += d.x * s; cam.origin.y += d.y * s; cam.origin.z += d.z * s; cam.origin.w += d.w * s; };
+    switch (camdir) {
+    case 0: axpy(cam.forward, -v); break;   // Forward: the camera looks along -forward
+    case 1: axpy(cam.forward, v); break;
+    case 2: axpy(cam.right, -v); break;
+    case 3: axpy(cam.right, v); break;
+    case 4: axpy(cam.up, v); break;
+    case 5: axpy(cam.up, -v); break;
+    }
+}
+void CameraManager::MouseMove(float xOffset, float yOffset) // camera.h:75-93
+{
+    moved = true;
+    xOffset *= mouseSensivity; yOffset *= mouseSensivity;
+    yaw_ = fmodf(yaw_ + xOffset, 360.f);
+    pitch_ += yOffset;
+    pitch_ = pitch_ < -89.f ? -89.f : (pitch_ > 89.f ? 89.f : pitch_);
+    const double yaw = (double)(yaw_ * 3.14159265358979323846264f) / 180.0, pitch = (double)(pitch_ * 3.14159265358979323846264f) / 180.0;
+    float3 f((float)(cos(yaw) * cos(pitch)), (float)sin(pitch), (float)(sin(yaw) * cos(pitch)));
+    cam.forward = to4(normalize(f));
+}
+void CameraManager::Zoom(float offset) { moved = true; Fov(cam.fov + offset); } // camera.h:95-99
+
 void CameraManager::UpdateCamVec() // camera.h:111-121
 {
     Fov(cam.fov);

@@ -102,6 +102,23 @@ class Device:
         self._chk(self._lib.rt_read_accum(self._h, _lib.ptr(out)))
         return out
 
+    def write_accum(self, accum):
+        a = np.ascontiguousarray(accum, dtype=np.float32)
+        assert a.shape == (self.height, self.width, 4)
+        self._chk(self._lib.rt_write_accum(self._h, _lib.ptr(a)))
+
+    def save_checkpoint(self, path, frames):
+        """{accum, seeds, frames}: everything a render carries from one frame to the next."""
+        np.savez_compressed(path, accum=self.read_accum(), seeds=self.get_seeds(), frames=np.int32(frames),
+                            dims=np.array([self.width, self.height, self.y0, self.y1], np.int32))
+
+    def load_checkpoint(self, path):
+        g = np.load(path)
+        assert tuple(g["dims"]) == (self.width, self.height, self.y0, self.y1), "checkpoint was taken with another frame/band"
+        self.write_accum(g["accum"])
+        self.set_seeds(g["seeds"])
+        return int(g["frames"])
+
     def postproc(self, frames, vignette=0.0, gamma=0.9, chromatic=0.0):
         """Renderer::PostProc + SaveFrame: returns (float image (H,W,4), RGBA8 image (H,W,4) uint8)."""
         f = np.zeros((self.height, self.width, 4), dtype=np.float32)
@@ -209,6 +226,18 @@ class Renderer:
         e = C.c_float(0)
         self._chk(self._lib.rth_renderer_read(self._h, _lib.ptr(out), C.byref(e)))
         return out, float(e.value)
+
+    def Move(self, camdir):
+        self._chk(self._lib.rth_renderer_camera_move(self._h, int(camdir)))
+
+    def MouseMove(self, dx, dy):
+        self._chk(self._lib.rth_renderer_camera_mouse(self._h, float(dx), float(dy)))
+
+    def Zoom(self, offset):
+        self._chk(self._lib.rth_renderer_camera_zoom(self._h, float(offset)))
+
+    def frames(self):
+        return int(self._lib.rth_renderer_frames(self._h))
 
     def SaveFrame(self, path):
         self._chk(self._lib.rth_renderer_save_frame(self._h, str(path).encode()))

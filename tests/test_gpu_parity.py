@@ -393,3 +393,44 @@ def test_config5_robo_orb_terrarium_tlas_sbvh():
     assert abs(dc["extend_node_visits"] - e["node_visits"]) <= 0.002 * e["node_visits"]
     assert dc["extend_tlas_visits"] > 0
     d.close()
+
+
+def test_checkpoint_resume_is_bit_exact(tmp_path):
+    """{accum, seeds, frames} is the whole cross-frame state: 2 frames + checkpoint + 2 frames in a new context == 4 frames."""
+    Wd, Hd = 96, 54
+    sa, cam, o, d = _pair(lambda: scenes.sponza_class(0.2), Wd, Hd, DEFAULT)
+    d.seed_default()
+    d.render(cam, 2)
+    ck = tmp_path / "ck.npz"
+    d.save_checkpoint(ck, frames=3)
+    d.close()
+    d2 = Device(Wd, Hd, **DEFAULT)
+    d2.upload(sa)
+    assert d2.load_checkpoint(ck) == 3
+    d2.render(cam, 2)
+    ref, seeds, *_ = o.render(cam, 4)
+    assert_bits(d2.read_accum(), ref, "resumed accumulator")
+    assert np.array_equal(d2.get_seeds(), seeds)
+    d2.close()
+
+
+def test_camera_controller_resets_accumulation():
+    s, view = scenes.cube_scene()
+    r = Renderer(s, 64, 36)
+    r.SetCamera(view["origin"], view["forward"], fov=view["fov"], aperture=view["aperture"])
+    r.Init()
+    r.Tick(3)
+    assert r.frames() == 4                       # frames starts at 1 and counts up (renderer.cpp:45,53)
+    a3, _ = r.read()
+    c0 = r.camera()
+    r.Move(3)                                    # CamDir::Right: origin += right * speed
+    r.Tick(1)
+    c1 = r.camera()
+    assert np.allclose(c1["origin"][:3] - c0["origin"][:3], c0["right"][:3], atol=1e-6)
+    assert r.frames() == 2                       # camera.moved -> reset kernel, frames = 1, then ++
+    a1, _ = r.read()
+    assert a1[..., :3].sum() < 0.6 * a3[..., :3].sum()
+    r.Zoom(-10.0)
+    r.Tick(1)
+    assert abs(float(r.camera()["fov"]) - (view["fov"] - 10.0)) < 1e-5 and r.frames() == 2
+    r.close()
