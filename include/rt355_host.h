@@ -40,6 +40,9 @@ int rth_load_model(RthScene* s, const char* filename, const char* defaultMateria
 int rth_save_png(const char* file, int width, int height, const RtFloat4* data);
 /* BVH2::BuildBLAS(true, startIdx) with bvh2->alpha = alpha (bvh.cpp:46-82). */
 int rth_build_blas(RthScene* s, int startIdx, float alpha);
+/* Threads for the following BuildBLAS calls: 1 = the reference's sequential loop; > 1 = task-parallel subtrees numbered
+ * afterwards in the reference's LIFO order (identical arrays). */
+int rth_set_build_threads(RthScene* s, int threads);
 int rth_build_bvh4(RthScene* s);            /* new BVH4(*bvh2) (scene.cpp:71)                    */
 int rth_build_tlas(RthScene* s);            /* new TLAS(*bvh2); Build() (renderer.cpp:12-13)     */
 int rth_set_instance_transform(RthScene* s, int blas, const float invT[16]); /* scene.cpp:82 (commented out there) */

@@ -69,7 +69,7 @@ HOST_SYMBOLS = [
     "rth_bvh2_nodes", "rth_bvh4_nodes", "rth_prim_idx", "rth_tlas_nodes", "rth_blas_nodes", "rth_bvh_stats", "rth_camera",
     "rth_renderer_create", "rth_renderer_destroy", "rth_renderer_init", "rth_renderer_set_camera", "rth_renderer_tick",
     "rth_renderer_read", "rth_renderer_camera", "rth_seed_stream", "rth_load_model", "rth_save_png",
-    "rth_renderer_save_frame", "rth_renderer_camera_move", "rth_renderer_camera_mouse", "rth_renderer_camera_zoom", "rth_renderer_frames"]
+    "rth_set_build_threads", "rth_renderer_save_frame", "rth_renderer_camera_move", "rth_renderer_camera_mouse", "rth_renderer_camera_zoom", "rth_renderer_frames"]
 
 _dev = None
 _host = None
@@ -150,6 +150,7 @@ def host_lib():
         lib.rth_add_triangles.argtypes = [vp, vp, vp, i32, cp, i32]
         lib.rth_build_blas.argtypes = [vp, i32, C.c_float]
         lib.rth_build_bvh4.argtypes = [vp]
+        lib.rth_set_build_threads.argtypes = [vp, i32]
         lib.rth_build_tlas.argtypes = [vp]
         lib.rth_set_instance_transform.argtypes = [vp, i32, fp]
         for n in ("rth_primitives", "rth_materials", "rth_textures", "rth_lights", "rth_bvh2_nodes", "rth_bvh4_nodes",

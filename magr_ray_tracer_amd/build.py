@@ -19,7 +19,7 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 # -ffp-contract=off + correctly rounded div/sqrt: the float discipline of oracle/oracle.c
 DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                 "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
-HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-pthread"]
 ORACLE_FLAGS = ["-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fopenmp", "-Wall", "-D_GNU_SOURCE"]
 
 

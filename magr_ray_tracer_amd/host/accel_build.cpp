@@ -11,9 +11,12 @@
 // needs the Windows/GL/OpenCL template headers), so node-array parity with it is
 // UNPINNED; traversal parity does not depend on it because the oracle and the HIP path
 // consume the same arrays.
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <future>
+#include <mutex>
 #include <utility>
 #include "rt_host.h"
 
@@ -123,7 +126,14 @@ void BVH2::BuildBLAS(bool statistics, int startIdx)
     bvhNodes[rootNodeIdx_].count = (uint32_t)refs.size();
     nodesUsed_++;
     UpdateNodeBounds(rootNodeIdx_, refs);
-    BuildBVH(rootNodeIdx_, std::move(refs));
+    if (buildThreads > 1 && refs.size() > 2048) {
+        const RtBVHNode2& rn = bvhNodes[rootNodeIdx_];
+        float d0 = rn.aabbMax.x - rn.aabbMin.x, d1 = rn.aabbMax.y - rn.aabbMin.y, d2 = rn.aabbMax.z - rn.aabbMin.z;
+        int budget = buildThreads - 1;
+        TNode* tree = BuildSubtree(std::move(refs), hi(0.f, d0 * d1 + d0 * d2 + d1 * d2), 0, budget);
+        FlattenLIFO(rootNodeIdx_, tree);
+    } else
+        BuildBVH(rootNodeIdx_, std::move(refs));
     if (statistics) {
         stat_build_time += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         stat_node_count = nodesUsed_;
@@ -164,7 +174,7 @@ void BVH2::BuildBVH(uint32_t root, Refs data)
         }
         Refs left, right;
         if (objectCost < spatialCost) ObjectSplit(objectAxis, objectPos, refs, left, right);
-        else { stat_spatial_splits++; SpatialSplit(spatialAxis, spatialPos, refs, left, right); }
+        else { stat_spatial_splits++; SpatialSplit(spatialAxis, spatialPos, refs, left, right, stat_prims_clipped); }
         // Termination guard (deviation from the reference, which recurses without bound here): a
         // spatial split that hands every reference to one child or duplicates all of them into both
         // makes no progress and would be chosen again for the child -> close the node as a leaf.
@@ -184,6 +194,88 @@ void BVH2::BuildBVH(uint32_t root, Refs data)
         work.emplace_back(leftId, std::move(left));
         work.emplace_back(rightId, std::move(right)); // popped first
     }
+}
+
+// ---- parallel build --------------------------------------------------------------------
+// A node's split decision depends only on its own references (and the BLAS root area / alpha), so subtrees can be built
+// by independent tasks into a pointer tree.  Node ids and the primIdx order are then produced by FlattenLIFO, which
+// replays the reference's work-stack order (children get the next two ids when their parent is popped, the right child
+// is popped first, leaves append their references when popped: bvh.cpp:101-154) — the arrays are identical to the
+// sequential build, index for index.
+struct BVH2::TNode {
+    float bmin[4], bmax[4];
+    TNode* left = nullptr; TNode* right = nullptr;
+    Refs refs;                    // leaf only
+    ~TNode() { delete left; delete right; }
+};
+static std::mutex g_statMutex;
+BVH2::TNode* BVH2::BuildSubtree(Refs refs, float rootArea, int depth, int& budget)
+{
+    TNode* n = new TNode();
+    n->bmin[0] = n->bmin[1] = n->bmin[2] = RT_REALLYFAR; n->bmin[3] = 0;
+    n->bmax[0] = n->bmax[1] = n->bmax[2] = -RT_REALLYFAR; n->bmax[3] = 0;
+    for (const BVHPrimData& r : refs) for (int k = 0; k < 4; k++) { n->bmin[k] = fminf(n->bmin[k], r.box.bmin[k]); n->bmax[k] = fmaxf(n->bmax[k], r.box.bmax[k]); }
+    int objectAxis = 0, spatialAxis = -1;
+    float objectPos = 0, overlap = 0, spatialPos = RT_REALLYFAR, spatialCost = RT_REALLYFAR;
+    float objectCost = FindBestObjectSplitPlane(objectAxis, objectPos, overlap, refs);
+    float ex = n->bmax[0] - n->bmin[0], ey = n->bmax[1] - n->bmin[1], ez = n->bmax[2] - n->bmin[2];
+    float leafCost = (float)(uint32_t)refs.size() * (ex * ey + ey * ez + ez * ex);
+    if (overlap / rootArea > alpha) spatialCost = FindBestSpatialSplitPlane(spatialAxis, spatialPos, refs);
+    if (refs.size() <= RT_MIN_LEAF_PRIMS || (leafCost < objectCost && leafCost < spatialCost)) { n->refs = std::move(refs); return n; }
+    Refs left, right;
+    uint32_t clipped = 0;
+    bool spatial = !(objectCost < spatialCost);
+    if (!spatial) ObjectSplit(objectAxis, objectPos, refs, left, right);
+    else {
+        SpatialSplit(spatialAxis, spatialPos, refs, left, right, clipped);
+        std::lock_guard<std::mutex> lock(g_statMutex);
+        stat_prims_clipped += clipped;
+    }
+    if (left.empty() || right.empty() || (left.size() >= refs.size() && right.size() >= refs.size())) {
+        { std::lock_guard<std::mutex> lock(g_statMutex); stat_forced_leaves++; if (spatial) { /* the sequential build counts the split before it is discarded */ stat_spatial_splits++; } }
+        n->refs = std::move(refs);
+        return n;
+    }
+    if (spatial) { std::lock_guard<std::mutex> lock(g_statMutex); stat_spatial_splits++; }
+    refs.clear(); refs.shrink_to_fit();
+    bool fork = false;
+    { std::lock_guard<std::mutex> lock(g_statMutex); if (budget > 0 && left.size() > 1024 && right.size() > 1024) { budget--; fork = true; } }
+    if (fork) {
+        auto fut = std::async(std::launch::async, [&, this]() { return BuildSubtree(std::move(left), rootArea, depth + 1, budget); });
+        n->right = BuildSubtree(std::move(right), rootArea, depth + 1, budget);
+        n->left = fut.get();
+        std::lock_guard<std::mutex> lock(g_statMutex); budget++;
+    } else {
+        n->left = BuildSubtree(std::move(left), rootArea, depth + 1, budget);
+        n->right = BuildSubtree(std::move(right), rootArea, depth + 1, budget);
+    }
+    return n;
+}
+void BVH2::FlattenLIFO(uint32_t root, TNode* tree)
+{
+    std::vector<std::pair<uint32_t, TNode*>> work;
+    work.emplace_back(root, tree);
+    auto setBounds = [&](uint32_t id, const TNode* t) {
+        if (id >= bvhNodes.size()) bvhNodes.resize((size_t)(bvhNodes.size() * 1.5));
+        bvhNodes[id].aabbMin = RtFloat4{ t->bmin[0], t->bmin[1], t->bmin[2], t->bmin[3] };
+        bvhNodes[id].aabbMax = RtFloat4{ t->bmax[0], t->bmax[1], t->bmax[2], t->bmax[3] };
+    };
+    while (!work.empty()) {
+        auto [id, t] = work.back();
+        work.pop_back();
+        if (!t->left) {
+            bvhNodes[id].first = (uint32_t)primIdx.size();
+            bvhNodes[id].count = (uint32_t)t->refs.size();
+            for (const BVHPrimData& r : t->refs) primIdx.push_back(r.idx);
+            continue;
+        }
+        uint32_t leftId = nodesUsed_++, rightId = nodesUsed_++;
+        setBounds(leftId, t->left); setBounds(rightId, t->right);
+        bvhNodes[id].first = leftId; bvhNodes[id].count = 0;
+        work.emplace_back(leftId, t->left);
+        work.emplace_back(rightId, t->right);
+    }
+    delete tree;
 }
 
 // ---- object splits -------------------------------------------------------------
@@ -366,7 +458,7 @@ float BVH2::FindBestSpatialSplitPlane(int& axis, float& splitPos, const Refs& re
     }
     return best;
 }
-void BVH2::SpatialSplit(int axis, float splitPos, const Refs& refs, Refs& left, Refs& right)
+void BVH2::SpatialSplit(int axis, float splitPos, const Refs& refs, Refs& left, Refs& right, uint32_t& clippedCount) const
 {
     for (const BVHPrimData& r : refs) {
         float mn = r.box.bmin[axis], mx = r.box.bmax[axis];
@@ -383,7 +475,7 @@ void BVH2::SpatialSplit(int axis, float splitPos, const Refs& refs, Refs& left, 
                 lok = ClipSphereToAABB(lclip, float3(prim.obj.sphere.pos), prim.obj.sphere.r, lout);
                 rok = ClipSphereToAABB(rclip, float3(prim.obj.sphere.pos), prim.obj.sphere.r, rout);
             }
-            stat_prims_clipped++;
+            clippedCount++;
             if (lok) left.push_back({ lout, r.idx });
             if (rok) right.push_back({ rout, r.idx });
         } else if (mx <= splitPos) left.push_back(r);

@@ -67,6 +67,7 @@ int rth_build_blas(RthScene* s, int startIdx, float alpha)
     if (!s || startIdx < 0 || startIdx >= (int)s->scene.primitives.size()) { g_herr = "rth_build_blas: bad start index"; return -1; }
     GUARD(s->scene.bvh2->alpha = alpha; s->scene.bvh2->BuildBLAS(true, startIdx))
 }
+int rth_set_build_threads(RthScene* s, int threads) { if (!s) return -1; s->scene.bvh2->buildThreads = threads < 1 ? 1 : threads; return 0; }
 int rth_build_bvh4(RthScene* s) { GUARD(s->scene.BuildBVH4()) }
 int rth_build_tlas(RthScene* s) { GUARD(delete s->tlas; s->tlas = new TLAS(*s->scene.bvh2); s->tlas->Build()) }
 int rth_set_instance_transform(RthScene* s, int blas, const float invT[16])

@@ -61,6 +61,7 @@ class BVH2 {
 public:
     BVH2(std::vector<RtPrimitive>& prims, std::vector<RtBVHInstance>& blasNodes);
     void     BuildBLAS(bool statistics, int startIdx);
+    int      buildThreads = 1;   // > 1: subtrees are built by parallel tasks, then numbered in the reference's LIFO order (same arrays)
     uint32_t Depth(uint32_t nodeIdx) const;
     uint32_t Count(uint32_t nodeIdx) const;
     float    TotalCost(uint32_t nodeIdx) const;
@@ -73,13 +74,16 @@ public:
 private:
     using Refs = std::vector<BVHPrimData>;
     void  BuildBVH(uint32_t root, Refs data);
+    struct TNode;                                       // temporary pointer tree of the parallel build
+    TNode* BuildSubtree(Refs refs, float rootArea, int depth, int& budget);
+    void  FlattenLIFO(uint32_t root, TNode* tree);
     void  UpdateNodeBounds(uint32_t nodeIdx, const Refs& prims);
     Refs  CreateBVHPrimData(int startIdx) const;
     float CalculateNodeCost(const RtBVHNode2& node, uint32_t count) const;
     float FindBestObjectSplitPlane(int& axis, float& splitPos, float& overlap, const Refs& prims) const;
     void  ObjectSplit(int axis, float splitPos, const Refs& prims, Refs& left, Refs& right) const;
     float FindBestSpatialSplitPlane(int& axis, float& splitPos, const Refs& prims) const;
-    void  SpatialSplit(int axis, float splitPos, const Refs& prims, Refs& left, Refs& right);
+    void  SpatialSplit(int axis, float splitPos, const Refs& prims, Refs& left, Refs& right, uint32_t& clippedCount) const;
     bool  ClipTriangleToAABB(const Aabb& bounds, float3 v0, float3 v1, float3 v2, Aabb& out) const;
     bool  ClipSphereToAABB(const Aabb& bounds, float3 pos, float r, Aabb& out) const;
     std::vector<RtPrimitive>& primitives_;

@@ -118,7 +118,9 @@ class Scene:
         return n
 
     # reference: BVH2::BuildBLAS (bvh.cpp:46-82), bvh2->alpha = 1 -> plain SAH BVH, 0 -> full SBVH
-    def BuildBLAS(self, startIdx=0, alpha=1.0):
+    def BuildBLAS(self, startIdx=0, alpha=1.0, threads=1):
+        """threads > 1: task-parallel build, numbered afterwards in the reference's LIFO order (identical arrays)."""
+        self._lib.rth_set_build_threads(self._h, int(threads))
         self._chk(self._lib.rth_build_blas(self._h, int(startIdx), float(alpha)))
 
     def BuildBVH4(self):

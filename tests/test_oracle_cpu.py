@@ -340,3 +340,27 @@ def test_config1_cube_256_cpu_plumbing():
     o.extend(rays)
     # (generate() jitters the lens even without AA, so compare statistically)
     assert abs((rays["primIdx"] != -1).mean() - hit.mean()) < 0.01
+
+
+@pytest.mark.parametrize("alpha", [1.0, 1e-5, 0.0])
+def test_parallel_build_is_index_exact(alpha):
+    """the task-parallel builder numbers nodes in the reference's LIFO order -> identical arrays."""
+    from magr_ray_tracer_amd.scene import Scene
+
+    def build(threads):
+        s = Scene()
+        scenes._std_materials(s)
+
+        def blob(U, V):
+            th, ph = U * 2 * np.pi, V * np.pi
+            r = 1.0 + 0.18 * np.sin(5 * th) * np.sin(3 * ph) ** 2
+            return r * np.sin(ph) * np.cos(th), 1.25 + r * np.cos(ph), r * np.sin(ph) * np.sin(th)
+        s.AddTriangles(scenes.param_surface(blob, 56, 56), "sand")
+        s.AddQuad((-10, 0, -10), (-10, 0, 10), (10, 0, 10), (10, 0, -10), "grey")
+        s.BuildBLAS(0, alpha, threads=threads)
+        return s.arrays(bvh4=False), s.stats()
+    a1, st1 = build(1)
+    a4, st4 = build(4)
+    assert a1.bvh2.tobytes() == a4.bvh2.tobytes() and np.array_equal(a1.primIdx, a4.primIdx)
+    for k in ("nodes", "depth", "spatial_splits", "prims_clipped"):
+        assert st1[k] == st4[k], k
