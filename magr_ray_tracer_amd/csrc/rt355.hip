@@ -151,7 +151,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     for (int k = 0; k < 2; k++) { QA(O[k], n); QA(D[k], n); QA(inten[k], n); QA(meta[k], n); QA(tile[k], nTiles + 2); QA(super[k], nTiles / 64 + 2); }
     QA(hit, n);
     QA(sA, nS); QA(sB, nS); QA(sC, nS);
-    QA(nRays, RT_MAX_BOUNCES + 2); QA(nShadow, RT_MAX_BOUNCES + 2); QA(cursor, 2 * (RT_MAX_BOUNCES + 2));
+    QA(nRays, RT_MAX_BOUNCES + 2); QA(nShadow, RT_MAX_BOUNCES + 2); QA(cursor, 2 * (RT_MAX_BOUNCES + 2)); QA(fault, 1);
     QA(seeds, n); QA(accum, (size_t)c.width * c.height);
     if (rc == RT_OK) rc = dalloc(bag, &ctx->dSteps, n);
     q.steps = nullptr;
@@ -164,6 +164,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     (void)hipMemsetAsync(q.nRays, 0, sizeof(int32_t) * (RT_MAX_BOUNCES + 2), ctx->stream);
     (void)hipMemsetAsync(q.nShadow, 0, sizeof(int32_t) * (RT_MAX_BOUNCES + 2), ctx->stream);
     (void)hipMemsetAsync(q.cursor, 0, sizeof(int32_t) * 2 * (RT_MAX_BOUNCES + 2), ctx->stream);
+    (void)hipMemsetAsync(q.fault, 0, sizeof(int32_t), ctx->stream);
     (void)hipMemsetAsync(q.ctrExtend, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
     (void)hipMemsetAsync(q.ctrConnect, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
     (void)hipMemsetAsync(q.seeds, 0, sizeof(uint32_t) * n, ctx->stream);
@@ -584,13 +585,23 @@ extern "C" int rt_render(RtCtx* ctx, const RtCamera* cam, const RtSettings* sett
     }
     return RT_OK;
 }
+static int check_fault(RtCtx* ctx) // after a stream sync: did a bounded device-side wait expire?
+{
+    int32_t f = 0;
+    HIPCHK(hipMemcpy(&f, ctx->q.fault, sizeof f, hipMemcpyDeviceToHost));
+    if (f) {
+        (void)hipMemset(ctx->q.fault, 0, sizeof f);
+        return fail(RT_E_DEVICE, "device fault %d: a bounded wait of the ordered scan in k_shade expired (results of this render are invalid)", f);
+    }
+    return RT_OK;
+}
 extern "C" int rt_synchronize(RtCtx* ctx)
 {
     if (!ctx) return fail(RT_E_INVALID, "rt_synchronize: null context");
     HIPCHK(hipSetDevice(ctx->cfg.device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ev_collect(ctx);
-    return RT_OK;
+    return check_fault(ctx);
 }
 
 extern "C" int rt_focus(RtCtx* ctx, int32_t x, int32_t y, const RtCamera* cam, float* t)
@@ -614,6 +625,7 @@ extern "C" int rt_read_accum(RtCtx* ctx, RtFloat4* out)
     HIPCHK(hipSetDevice(ctx->cfg.device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ev_collect(ctx);
+    int rc = check_fault(ctx); if (rc) return rc;
     HIPCHK(hipMemcpy(out, ctx->q.accum, sizeof(float4) * (size_t)ctx->cfg.width * ctx->cfg.height, hipMemcpyDeviceToHost));
     return RT_OK;
 }

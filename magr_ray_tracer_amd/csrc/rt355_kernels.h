@@ -65,6 +65,7 @@ struct DevQueues {
     unsigned long long* super[2];   // [s] = status of super-tile s (64 consecutive tiles), same encoding
     int32_t* nRays;    // [RT_MAX_BOUNCES+2]  rays entering bounce b
     int32_t* nShadow;  // [RT_MAX_BOUNCES+2]  shadow rays of bounce b occupy [nShadow[b], nShadow[b+1])
+    int32_t* fault;    // [1] set to 1 by a kernel whose bounded wait expired (host turns it into RT_E_DEVICE)
     int32_t* cursor;   // [2*(RT_MAX_BOUNCES+2)] work-queue heads of the persistent kernels (extend: [b], connect: [9+b])
     uint32_t* seeds;   // one RNG stream per band slot
     float4* accum;     // full frame, indexed by global pixel index
@@ -872,7 +873,7 @@ RT_FORCEINLINE float4 shade_hit(const DevScene& sc, const DevVariant& var, SRay&
 // Tile status word of the decoupled look-back scan: [63:62] flag (0 empty, 1 aggregate, 2 inclusive
 // prefix), [61:31] extension-ray count, [30:0] shadow-ray count.  Flag and payload travel in ONE 8-byte
 // word written/read with agent-scope atomics (L2-coherent across XCDs), so no separate fence is needed.
-static constexpr unsigned long long kTileAgg = 1ull << 62, kTilePrefix = 2ull << 62;
+static constexpr unsigned long long kTileAgg = 1ull << 62, kTilePrefix = 2ull << 62, kTilePrefixZero = 2ull << 62;
 RT_FORCEINLINE unsigned long long tile_pack(unsigned long long flag, uint32_t e, uint32_t s) { return flag | ((unsigned long long)e << 31) | (unsigned long long)s; }
 RT_FORCEINLINE uint32_t tile_ext(unsigned long long v) { return (uint32_t)((v >> 31) & 0x7fffffffull); }
 RT_FORCEINLINE uint32_t tile_sh(unsigned long long v) { return (uint32_t)(v & 0x7fffffffull); }
@@ -883,6 +884,21 @@ RT_FORCEINLINE uint32_t tile_sh(unsigned long long v) { return (uint32_t)(v & 0x
 // induction over the tile id every wait ends as long as the G workgroups can be co-resident — the host launches
 // G <= 4 per CU, half of what this kernel's registers/LDS admit, and uses no ticket atomics (8,100 tickets on
 // one word cost ~90 us per launch on this chip, more than the shading itself).
+// Bounded wait on a status word: every spin in this library has an upper bound (~seconds), after which the kernel raises
+// q.fault and carries on with a zero payload instead of hanging the GPU; the host reports RT_E_DEVICE.
+static constexpr uint32_t kSpinLimit = 1u << 23;
+RT_FORCEINLINE unsigned long long wait_word(const unsigned long long* p, unsigned long long needFlag /*0: any non-empty, 2: prefix*/, int32_t* fault)
+{
+    unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t spins = 0;
+    while (needFlag == 2ull ? (v >> 62) != 2ull : (v >> 62) == 0ull) {
+        if (++spins > kSpinLimit) { *fault = 1; return needFlag == 2ull ? kTilePrefixZero : kTilePrefixZero; }
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return v;
+}
+
 template <bool NEE>
 __global__ __launch_bounds__(kBlock, 5) void k_shade(DevScene sc, DevQueues q, DevVariant var, int bounce)
 {
@@ -964,8 +980,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_shade(DevScene sc, DevQueues q, D
                 unsigned long long v = 0ull;
                 if ((uint32_t)lane < inSup) {
                     const uint32_t t = (sup << 6) + (uint32_t)lane;
-                    v = __hip_atomic_load(&state[1 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    while ((v >> 62) == 0ull) { __builtin_amdgcn_s_sleep(1); v = __hip_atomic_load(&state[1 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    v = wait_word(&state[1 + t], 0ull, q.fault);
                 }
                 inE = tile_ext(v); inS = tile_sh(v);
 #pragma unroll
@@ -982,8 +997,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_shade(DevScene sc, DevQueues q, D
                         const int t = top - lane;
                         unsigned long long v = kTilePrefix;
                         if (t >= 0) {
-                            v = __hip_atomic_load(&super[cur][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            while ((v >> 62) == 0ull) { __builtin_amdgcn_s_sleep(1); v = __hip_atomic_load(&super[cur][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                            v = wait_word(&super[cur][t], 0ull, q.fault);
                         }
                         const unsigned long long isPre = __ballot((v >> 62) == 2ull);
                         const int stop = isPre ? __ffsll((long long)isPre) - 1 : 64;
@@ -999,8 +1013,7 @@ __global__ __launch_bounds__(kBlock, 5) void k_shade(DevScene sc, DevQueues q, D
             } else if (sup > 0) {
                 unsigned long long v = 0ull;
                 if (lane == 0) {
-                    v = __hip_atomic_load(&super[cur][sup - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    while ((v >> 62) != 2ull) { __builtin_amdgcn_s_sleep(1); v = __hip_atomic_load(&super[cur][sup - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    v = wait_word(&super[cur][sup - 1], 2ull, q.fault);
                 }
                 preE = tile_ext(v); preS = tile_sh(v);            // lane 0 holds it; only lane 0 uses it below
             }
