@@ -169,11 +169,24 @@ def _seed_stream(out, first):
         raise RuntimeError("rth_seed_stream failed")
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota (a GPU box exposes all
+    logical CPUs but grants a share; oversubscribing it would make the baseline look slower than the hardware is)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(sa, cam, W, H, accel):
     """The oracle (CPU restatement of the reference path, kind "port") timed on this box's host cores on a bounded
     sample of the same workload: full-resolution frames, row-band parallel over all cores."""
     from oracle.oracle_py import Oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     o = Oracle(sa, W, H, accel=accel)
     t0 = time.perf_counter()
     o.render(cam, 1, threads=cores)
