@@ -59,7 +59,7 @@ MAX_BOUNCES = 7
 DEVICE_SYMBOLS = [
     "rt_last_error", "rt_device_count", "rt_create", "rt_destroy", "rt_upload_scene", "rt_set_seeds", "rt_seed_default",
     "rt_get_seeds", "rt_bind_accum", "rt_accum_device_ptr", "rt_stream", "rt_reset", "rt_render", "rt_synchronize", "rt_focus",
-    "rt_read_accum", "rt_write_accum", "rt_postproc", "rt_read_counters", "rt_reset_counters", "rt_read_stage_times", "rt_reset_stage_times",
+    "rt_read_accum", "rt_write_accum", "rt_postproc", "rt_read_counters", "rt_reset_counters", "rt_read_stage_times", "rt_reset_stage_times", "rt_set_profile",
     "rt_stage_begin_frame", "rt_stage_generate", "rt_stage_extend", "rt_stage_shade", "rt_stage_connect",
     "rt_debug_get_rays", "rt_debug_set_rays", "rt_debug_get_shadow", "rt_debug_enable_steps", "rt_debug_get_steps"]
 HOST_SYMBOLS = [
@@ -117,6 +117,7 @@ def device_lib():
         lib.rt_reset_counters.argtypes = [vp]
         lib.rt_read_stage_times.argtypes = [vp, vp]
         lib.rt_reset_stage_times.argtypes = [vp]
+        lib.rt_set_profile.argtypes = [vp, i32]
         lib.rt_stage_begin_frame.argtypes = [vp]
         lib.rt_stage_generate.argtypes = [vp, vp, vp]
         lib.rt_stage_extend.argtypes = [vp, i32, i32]

@@ -75,35 +75,49 @@ static void free_bag(std::vector<void*>& bag) { for (void* p : bag) (void)hipFre
 static size_t stack_bytes(const RtCtx* c) { return (size_t)c->stackEntries * kBlock * sizeof(uint32_t); }
 
 // ---- profiling brackets --------------------------------------------------------------
+// Stage timing: a fixed ring of HIP event pairs on the context's stream.  Recording never forces a device sync: when the ring
+// wraps, the oldest pair is harvested (it completed thousands of launches ago; if not, the HOST waits on that one event while the
+// GPU keeps draining its queue).
+static constexpr size_t kEvRing = 4096;
+static void ev_account(RtCtx* c, RtCtx::Ev& e)
+{
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) { (void)hipEventSynchronize(e.b); (void)hipEventElapsedTime(&ms, e.a, e.b); }
+    switch (e.stage) {
+    case ST_GENERATE: c->times.generate_ms += ms; c->times.generate_launches++; break;
+    case ST_EXTEND:   c->times.extend_ms += ms; c->times.extend_launches++; break;
+    case ST_SHADE:    c->times.shade_ms += ms; c->times.shade_launches++; break;
+    case ST_COMPACT:  c->times.compact_ms += ms; c->times.compact_launches++; break;
+    case ST_CONNECT:  c->times.connect_ms += ms; c->times.connect_launches++; break;
+    case ST_ACCUM:    c->times.accumulate_ms += ms; c->times.accumulate_launches++; break;
+    }
+    e.stage = -1;
+}
+static void ev_init(RtCtx* c)   // rt_create, so that no event is created inside a timed region
+{
+    if (!c->cfg.profile || !c->evPool.empty()) return;
+    c->evPool.resize(kEvRing);
+    for (auto& e : c->evPool) { (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); e.stage = -1; }
+}
+static inline bool ev_on(const RtCtx* c, int stage) { return c->cfg.profile >= 2 || (c->cfg.profile == 1 && stage == ST_EXTEND); }
 static void ev_begin(RtCtx* c, int stage)
 {
-    if (!c->cfg.profile) return;
-    if (c->evUsed == c->evPool.size()) {
-        RtCtx::Ev e{}; (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); c->evPool.push_back(e);
-    }
-    c->evPool[c->evUsed].stage = stage;
-    (void)hipEventRecord(c->evPool[c->evUsed].a, c->stream);
+    if (!ev_on(c, stage)) return;
+    ev_init(c);
+    RtCtx::Ev& e = c->evPool[c->evUsed % kEvRing];
+    if (e.stage >= 0) ev_account(c, e);   // ring wrapped: harvest the oldest pair first
+    e.stage = stage;
+    (void)hipEventRecord(e.a, c->stream);
 }
-static void ev_end(RtCtx* c)
+static void ev_end(RtCtx* c, int stage)
 {
-    if (!c->cfg.profile) return;
-    (void)hipEventRecord(c->evPool[c->evUsed].b, c->stream);
+    if (!ev_on(c, stage)) return;
+    (void)hipEventRecord(c->evPool[c->evUsed % kEvRing].b, c->stream);
     c->evUsed++;
 }
 static void ev_collect(RtCtx* c) // call after a stream sync
 {
-    for (size_t i = 0; i < c->evUsed; i++) {
-        float ms = 0; (void)hipEventElapsedTime(&ms, c->evPool[i].a, c->evPool[i].b);
-        switch (c->evPool[i].stage) {
-        case ST_GENERATE: c->times.generate_ms += ms; c->times.generate_launches++; break;
-        case ST_EXTEND:   c->times.extend_ms += ms; c->times.extend_launches++; break;
-        case ST_SHADE:    c->times.shade_ms += ms; c->times.shade_launches++; break;
-        case ST_COMPACT:  c->times.compact_ms += ms; c->times.compact_launches++; break;
-        case ST_CONNECT:  c->times.connect_ms += ms; c->times.connect_launches++; break;
-        case ST_ACCUM:    c->times.accumulate_ms += ms; c->times.accumulate_launches++; break;
-        }
-    }
-    c->evUsed = 0;
+    for (auto& e : c->evPool) if (e.stage >= 0) ev_account(c, e);
 }
 
 // ---- create / destroy ----------------------------------------------------------------
@@ -174,6 +188,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     }
     (void)hipMemsetAsync(q.hit, 0, sizeof(float4) * n, ctx->stream);
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    ev_init(ctx);
     *out = ctx;
     return RT_OK;
 }
@@ -479,7 +494,7 @@ extern "C" int rt_stage_generate(RtCtx* ctx, const RtCamera* cam, const RtSettin
     if (!ctx || !cam) return fail(RT_E_INVALID, "rt_stage_generate: null argument");
     ev_begin(ctx, ST_GENERATE);
     hipLaunchKernelGGL(k_generate, grid_for(ctx->nPix), dim3(kBlock), 0, ctx->stream, ctx->q, *cam, s ? s->antiAliasing : 1);
-    ev_end(ctx);
+    ev_end(ctx, ST_GENERATE);
     HIPCHK(hipGetLastError());
     ctx->primaryRays += (uint64_t)ctx->nPix;
     ctx->generated = true;
@@ -505,7 +520,7 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
         hipLaunchKernelGGL((k_extend<RT_ACCEL_BVH2, 1>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
     else
         hipLaunchKernelGGL((k_extend<RT_ACCEL_BVH2, 0>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
-    ev_end(ctx);
+    ev_end(ctx, ST_EXTEND);
     HIPCHK(hipGetLastError());
     return RT_OK;
 }
@@ -526,7 +541,7 @@ extern "C" int rt_stage_shade(RtCtx* ctx, int32_t bounce)
         hipLaunchKernelGGL(k_shade<true>, sg, dim3(kBlock), 0, ctx->stream, ctx->sc, ctx->q, ctx->var, bounce);
     else
         hipLaunchKernelGGL(k_shade<false>, sg, dim3(kBlock), 0, ctx->stream, ctx->sc, ctx->q, ctx->var, bounce);
-    ev_end(ctx);
+    ev_end(ctx, ST_SHADE);
     ctx->shadeRun[bounce] = true;
     HIPCHK(hipGetLastError());
     return RT_OK;
@@ -552,11 +567,11 @@ extern "C" int rt_stage_connect(RtCtx* ctx, int32_t b0, int32_t b1)
         hipLaunchKernelGGL((k_connect<RT_ACCEL_BVH2, 1>), grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
     else
         hipLaunchKernelGGL((k_connect<RT_ACCEL_BVH2, 0>), grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
-    ev_end(ctx);
+    ev_end(ctx, ST_CONNECT);
     ev_begin(ctx, ST_ACCUM);
     for (int b = b0; b <= b1; b++)
         hipLaunchKernelGGL(k_accumulate, grid_for(ctx->nPix), dim3(kBlock), 0, ctx->stream, ctx->q, b);
-    ev_end(ctx);
+    ev_end(ctx, ST_ACCUM);
     HIPCHK(hipGetLastError());
     return RT_OK;
 }
@@ -581,7 +596,6 @@ extern "C" int rt_render(RtCtx* ctx, const RtCamera* cam, const RtSettings* sett
         }
         if (rr && nee && !renderBVH) if ((rc = rt_stage_connect(ctx, 0, ctx->cfg.max_bounces - 1))) return rc; // renderer.cpp:91-92
         ctx->frames++;
-        if (ctx->cfg.profile && ctx->evUsed > 4096) { HIPCHK(hipStreamSynchronize(ctx->stream)); ev_collect(ctx); }
     }
     return RT_OK;
 }
@@ -679,6 +693,16 @@ extern "C" int rt_read_stage_times(RtCtx* ctx, RtStageTimes* out)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ev_collect(ctx);
     *out = ctx->times;
+    return RT_OK;
+}
+extern "C" int rt_set_profile(RtCtx* ctx, int32_t level)
+{
+    if (!ctx || level < 0 || level > 2) return fail(RT_E_INVALID, "rt_set_profile: level must be 0, 1 or 2");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ev_collect(ctx);
+    ctx->cfg.profile = level;
+    ev_init(ctx);
     return RT_OK;
 }
 extern "C" int rt_reset_stage_times(RtCtx* ctx)

@@ -23,7 +23,7 @@ class Device:
         cfg["width"], cfg["height"], cfg["y0"], cfg["y1"] = width, height, y0, height if y1 is None else y1
         cfg["max_bounces"], cfg["shading"], cfg["sampling"], cfg["accel"] = max_bounces, shading, sampling, accel
         cfg["russian_roulette"], cfg["filter_fireflies"] = int(russian_roulette), int(filter_fireflies)
-        cfg["device"], cfg["profile"], cfg["extend_variant"] = device, int(profile), extend_variant
+        cfg["device"], cfg["profile"], cfg["extend_variant"] = device, (2 if profile is True else int(profile)), extend_variant
         self.cfg = cfg
         self.width, self.height = width, height
         self.y0, self.y1 = int(cfg["y0"]), int(cfg["y1"])
@@ -138,6 +138,9 @@ class Device:
         t = np.zeros((), dtype=_lib.StageTimes)
         self._chk(self._lib.rt_read_stage_times(self._h, t.ctypes.data_as(C.c_void_p)))
         return {k: (float(t[k]) if k.endswith("_ms") else int(t[k])) for k in t.dtype.names}
+
+    def set_profile(self, level):
+        self._chk(self._lib.rt_set_profile(self._h, int(level)))
 
     def reset_stage_times(self):
         self._chk(self._lib.rt_reset_stage_times(self._h))
