@@ -512,6 +512,10 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
     // bounce 0: primary rays are coherent and finish together, refilling buys nothing -> one ray per lane
     if (ctx->persist && (bounce > 0 || ctx->cfg.extend_variant == 3))
         hipLaunchKernelGGL((k_trace_persist<false>), dim3(ctx->persistGrid), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+    else if (ctx->persist && ctx->cfg.extend_variant != 5)
+        // bounce 0 through the same kernel with one workgroup per 256 rays: its "queue not longer than the grid" branch is the plain
+        // one-ray-per-lane loop without the TLAS code of k_extend (60 instead of 86 VGPRs: 8 instead of 5 waves per SIMD)
+        hipLaunchKernelGGL((k_trace_persist<false>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4 && ctx->layout == 1)
         hipLaunchKernelGGL((k_extend<RT_ACCEL_BVH4, 1>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4)
