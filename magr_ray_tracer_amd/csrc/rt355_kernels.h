@@ -886,14 +886,15 @@ RT_FORCEINLINE uint32_t tile_sh(unsigned long long v) { return (uint32_t)(v & 0x
 // one word cost ~90 us per launch on this chip, more than the shading itself).
 // Bounded wait on a status word: every spin in this library has an upper bound (~seconds), after which the kernel raises
 // q.fault and carries on with a zero payload instead of hanging the GPU; the host reports RT_E_DEVICE.
-static constexpr uint32_t kSpinLimit = 1u << 23;
+static constexpr uint32_t kSpinLimit = 1u << 22;   // x ~1-2 us per poll: several seconds
 RT_FORCEINLINE unsigned long long wait_word(const unsigned long long* p, unsigned long long needFlag /*0: any non-empty, 2: prefix*/, int32_t* fault)
 {
     unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t spins = 0;
     while (needFlag == 2ull ? (v >> 62) != 2ull : (v >> 62) == 0ull) {
-        if (++spins > kSpinLimit) { *fault = 1; return needFlag == 2ull ? kTilePrefixZero : kTilePrefixZero; }
-        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit) { *fault = 1; return kTilePrefixZero; }
+        // back off: a few quick polls, then ~1 us naps, so that thousands of waiting waves do not flood the L2 with polls
+        if (spins < 4) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
         v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return v;
