@@ -487,3 +487,64 @@ def test_config5_4k_frame_runs_and_is_deterministic():
     rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)
     assert (rel > 1e-4).mean() < 2e-3
     d.close()
+
+
+def test_fewer_bounces_no_aa_and_fisheye():
+    Wd, Hd = 128, 72
+    # max_bounces = 3 (host loop count), anti-aliasing off
+    v = dict(DEFAULT, max_bounces=3)
+    sa, cam, o, d = _pair(lambda: scenes.sponza_class(0.2), Wd, Hd, v)
+    acc, seeds, e, c = o.render(cam, 2, antiAliasing=0)
+    d.seed_default()
+    d.render(cam, 2, antiAliasing=0)
+    assert_bits(d.read_accum(), acc, "3 bounces, no AA")
+    assert np.array_equal(d.get_seeds(), seeds)
+    _ctr_equal(d.counters(), e, c)
+    d.close()
+    # fisheye camera (camera.cl:25-44): sin/cos -> 1e-4 tolerance; rays outside the unit disc are zero rays
+    s, view = scenes.cube_scene()
+    sa = s.arrays()
+    cam = scenes.make_camera(Wd, Hd, view["origin"], view["forward"], fov=60.0, aperture=0.0, type=1)
+    o = Oracle(sa, Wd, Hd, **DEFAULT)
+    d = Device(Wd, Hd, **DEFAULT)
+    d.upload(sa)
+    acc, *_ = o.render(cam, 2)
+    d.seed_default()
+    d.render(cam, 2)
+    got = d.read_accum()
+    rel = np.abs(got - acc) / np.maximum(np.abs(acc), 1e-3)
+    assert (rel > 1e-4).mean() < 2e-3 and np.isfinite(got).all() and got[..., :3].sum() > 0
+    d.close()
+
+
+def test_instance_transform_non_identity_bit_exact():
+    """transformRay/transformPosition (tlas.cl:3-8, util.cl:61-87) with a real inverse transform on one instance."""
+    Wd, Hd = 128, 72
+    from magr_ray_tracer_amd.scenes import Scene, _std_materials, box_tris
+    s = Scene()
+    _std_materials(s)
+    s.AddTriangles(box_tris((-2.4, 0, -0.8), (-0.9, 1.4, 0.6)), "red")
+    s.AddQuad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6), "grey")
+    s.AddQuad((-1, 4, -1), (1, 4, -1), (1, 4, 1), (-1, 4, 1), "white-light")
+    s.BuildBLAS(0, 1.0)
+    st = s.num_prims
+    s.AddTriangles(box_tris((0.5, 0.2, -0.7), (1.9, 1.8, 0.7)), "green")
+    s.BuildBLAS(st, 1.0)
+    a = np.deg2rad(17.0)
+    rot = np.array([[np.cos(a), 0, np.sin(a), 0.13], [0, 1, 0, -0.07], [-np.sin(a), 0, np.cos(a), 0.05], [0, 0, 0, 1]], np.float32)
+    s.SetInstanceTransform(1, rot)      # this IS invT (world -> instance), as the reference stores it
+    sa = s.arrays()
+    assert not np.allclose(sa.blas["invT"][1].reshape(4, 4), np.eye(4))
+    view = dict(origin=(0.4, 2.2, 5.5), forward=(0.05, 0.2, 0.97), fov=65.0, aperture=0.02)
+    cam = scenes.camera_for(view, Wd, Hd)
+    for accel in (0, 1):
+        v = dict(DEFAULT, accel=accel)
+        o = Oracle(sa, Wd, Hd, **v)
+        d = Device(Wd, Hd, **v)
+        d.upload(sa)
+        acc, seeds, e, c = o.render(cam, 2)
+        d.seed_default()
+        d.render(cam, 2)
+        assert_bits(d.read_accum(), acc, f"rotated instance, accel={accel}")
+        _ctr_equal(d.counters(), e, c)
+        d.close()
