@@ -47,7 +47,7 @@ struct RtCtx {
     bool cursorUsed[2 * (RT_MAX_BOUNCES + 2)] = {};   // work-queue heads consumed since the last k_begin_frame
     bool shadeRun[RT_MAX_BOUNCES + 1] = {};           // shade(b) launched since the last k_begin_frame
     bool generated = false;                           // generate launched since the last k_begin_frame
-    int stackEntries = RT_BVH2_STACK, persistGrid = 0;
+    int stackEntries = RT_BVH2_STACK, persistGrid = 0, persistGridConnect = 0;
     PersistTune tune{ 64, 20, 6, 8 };
     float4* dPostF = nullptr; uchar4* dPostB = nullptr;   // post-processing outputs (lazy)
     int32_t* dSteps = nullptr;   // per-ray `steps` buffer, only bound while rt_debug_enable_steps is on
@@ -403,11 +403,14 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         HIPCHK(hipGetDeviceProperties(&prop, ctx->cfg.device));
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_persist<false>, kBlock, stack_bytes(ctx)));
         ctx->persistGrid = std::min(ctx->gridMax, std::max(1, perCU) * prop.multiProcessorCount);
+        // the any-hit instantiation needs ~100 SGPRs: the hardware admits one workgroup per CU fewer than the occupancy query reports
+        // (MI355X_MICROARCH.md, residency); a surplus workgroup would strand its static first chunk until another one exits
+        ctx->persistGridConnect = std::min(ctx->gridMax, std::max(1, perCU - 1) * prop.multiProcessorCount);
         if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner,leafK[,blocksPerCU]" (tuning aid)
             int a = 0, b = 0, c = 0, l = 0, d = 0;
             int k = sscanf(t, "%d,%d,%d,%d,%d", &a, &b, &c, &l, &d);
             if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = PersistTune{ a, b, c, l };
-            if (k == 5 && d > 0) ctx->persistGrid = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount);
+            if (k == 5 && d > 0) ctx->persistGrid = ctx->persistGridConnect = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount);
         }
     }
     ctx->sc = sc;
@@ -562,7 +565,7 @@ extern "C" int rt_stage_connect(RtCtx* ctx, int32_t b0, int32_t b1)
     }
     ev_begin(ctx, ST_CONNECT);
     if (ctx->persist)
-        hipLaunchKernelGGL((k_trace_persist<true>), dim3(ctx->persistGrid), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1, 0, ctx->tune);
+        hipLaunchKernelGGL((k_trace_persist<true>), dim3(ctx->persistGridConnect), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1, 0, ctx->tune);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4 && ctx->layout == 1)
         hipLaunchKernelGGL((k_connect<RT_ACCEL_BVH4, 1>), grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4)
