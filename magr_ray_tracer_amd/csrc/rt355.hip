@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -326,6 +327,19 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
     if (rc == RT_OK) rc = upload(ctx, &sc.primIdx, primIdx, (size_t)nIdx);
     if (rc == RT_OK) rc = upload(ctx, &sc.tlas, tlas, (size_t)nTlas);
     if (rc == RT_OK) rc = upload(ctx, &sc.blas, blas, (size_t)nBlas);
+    if (rc == RT_OK) { // dense shading records (k_shade): geometric normal + material id + type per primitive
+        std::vector<float4> recs((size_t)nPrims);
+        for (int32_t i = 0; i < nPrims; i++) {
+            const RtPrimitive& p = prims[i];
+            const RtFloat4 N = p.objType == RT_PRIM_TRIANGLE ? p.obj.triangle.N : (p.objType == RT_PRIM_PLANE ? p.obj.plane.N : RtFloat4{ 0, 0, 0, 0 });
+            uint32_t tag = ((uint32_t)p.objType << 28) | ((uint32_t)p.matIdx & 0x07ffffffu) | (std::signbit(N.w) ? 0x08000000u : 0u);
+            // a triangle/plane normal with a non-zero w lane cannot be represented: mark it like a sphere (reference-layout path)
+            if (p.objType != RT_PRIM_SPHERE && N.w != 0.0f) tag = ((uint32_t)RT_PRIM_SPHERE << 28) | ((uint32_t)p.matIdx & 0x07ffffffu);
+            float w; memcpy(&w, &tag, 4);
+            recs[(size_t)i] = make_float4(N.x, N.y, N.z, w);
+        }
+        rc = upload(ctx, &sc.shadeRecs, recs.data(), recs.size());
+    }
     // Derived layout 1 (rt355_kernels.h, traverse_bvh2_packed): only for BVH2, when the encodings fit.
     ctx->layout = 0;
     if (rc == RT_OK && ctx->cfg.accel == RT_ACCEL_BVH2 && ctx->cfg.extend_variant != 1 && nIdx < (1 << 24)) {

@@ -51,6 +51,7 @@ struct DevScene {
     const float4*        pairs;      // [nNodes][4]  both child boxes + encoded child entries of interior node i
     const float4*        triRecs;    // [nIdx][3]    leaf-ordered triangle vertices + primitive id
     const uint32_t*      rootEntry;  // [nBlas]      encoded root of every instance
+    const float4*        shadeRecs;  // [nPrims]     {N.xyz, bits(matIdx | (N.w is -0) << 27 | objType << 28)}: what shade() needs of a 128-B Primitive, in 16 B
     const float4*        quads;      // [nNodes][8]  layout 1 of the BVH4: four child boxes + four encoded child entries (128 B)
     int32_t nLights, nPrims, nBlas;
 };
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
 // ------------------------------------------------------------------ shading helpers
 struct SRay { // the reference Ray fields shade() reads and writes
     float4 O, D, N, I, inten;
-    float t, u, v; int prim, bounces, pixel; bool inside, lastSpec;
+    float t, u, v; int prim, bounces, pixel, matIdx; bool inside, lastSpec;
 };
 struct ExtRay { float4 O, D, inten; int bounces; bool inside, lastSpec, valid; };
 
@@ -809,7 +810,7 @@ template <bool NEE>
 RT_FORCEINLINE float4 shade_hit(const DevScene& sc, const DevVariant& var, SRay& ray, uint32_t& seed, ExtRay& ext, ShadowOut& sh)
 {
     const RtPrimitive* prim = sc.prims + ray.prim;
-    const RtMaterial* mat = sc.mats + prim->matIdx;
+    const RtMaterial* mat = sc.mats + ray.matIdx;
     if (mat->isLight) {
         if (NEE && !ray.lastSpec) return splat(0.0f);
         return mul4(ray.inten, ld4(mat->emittance));
@@ -941,7 +942,13 @@ __global__ __launch_bounds__(kBlock, 5) void k_shade(DevScene sc, DevQueues q, D
             } else {
                 // what extend() leaves in the ray (wavefront.cl:69-72)
                 ray.I = add4(ray.O, muls(ray.D, ray.t));
-                ray.N = prim_normal(sc.prims + ray.prim, ray.I);
+                // normal and material id from the dense 16-byte shading record (4 MB for 265k primitives: L2-resident) instead
+                // of two fields 68 bytes apart in the 128-byte Primitive (34 MB); spheres need the hit point: reference layout
+                const float4 rec = sc.shadeRecs[ray.prim];
+                const uint32_t tag = __float_as_uint(rec.w);
+                ray.matIdx = (int)(tag & 0x07ffffffu);
+                ray.N = (tag >> 28) == RT_PRIM_SPHERE ? prim_normal(sc.prims + ray.prim, ray.I)
+                                                      : mk4(rec.x, rec.y, rec.z, (tag & 0x08000000u) ? -0.0f : 0.0f);   // flipped normals carry w = -0
                 if (dot4(ray.N, neg4(ray.D)) < 0) ray.N = muls(ray.N, -1.0f);
                 uint32_t seed = q.seeds[i];
                 float4 color = shade_hit<NEE>(sc, var, ray, seed, ext, sh);
