@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/rt355.h"
@@ -122,6 +123,7 @@ static void ev_collect(RtCtx* c) // call after a stream sync
 }
 
 // ---- create / destroy ----------------------------------------------------------------
+static void ctx_free(RtCtx* ctx);
 extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
 {
     if (!cfg || !out) return fail(RT_E_INVALID, "rt_create: null argument");
@@ -139,7 +141,8 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
         return fail(RT_E_DEVICE, "rt_create: no HIP device visible (this library has no CPU path)");
     if (c.device < 0 || c.device >= ndev) return fail(RT_E_INVALID, "rt_create: device %d out of range (%d visible)", c.device, ndev);
     HIPCHK(hipSetDevice(c.device));
-    RtCtx* ctx = new RtCtx();
+    std::unique_ptr<RtCtx, void (*)(RtCtx*)> guard(new RtCtx(), ctx_free);   // released on success; any early return frees it
+    RtCtx* ctx = guard.get();
     ctx->cfg = c;
     ctx->nPix = (c.y1 - c.y0) * c.width;
     ctx->firstPixel = c.y0 * c.width;
@@ -156,7 +159,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
         if (const char* g = getenv("RT355_SHADE_PER_CU")) { int v = atoi(g); if (v > 0 && v <= std::max(1, perCU - 1)) ctx->shadeGrid = prop.multiProcessorCount * v; }
     }
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete ctx; return fail(RT_E_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) return fail(RT_E_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e));
     DevQueues& q = ctx->q;
     const size_t n = (size_t)ctx->nPix, nS = n * (size_t)c.max_bounces;
     int rc = RT_OK;
@@ -173,7 +176,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     QA(ctrExtend, (size_t)ctx->gridMax * 5); QA(ctrConnect, (size_t)ctx->gridMax * 5);
 #undef QA
     if (rc == RT_OK) rc = dalloc(bag, &ctx->dFocus, 1);
-    if (rc != RT_OK) { free_bag(bag); (void)hipStreamDestroy(ctx->stream); delete ctx; return rc; }
+    if (rc != RT_OK) return rc;
     q.nPix = ctx->nPix; q.firstPixel = ctx->firstPixel; q.width = c.width; q.height = c.height;
     (void)hipMemsetAsync(q.accum, 0, sizeof(float4) * (size_t)c.width * c.height, ctx->stream);
     (void)hipMemsetAsync(q.nRays, 0, sizeof(int32_t) * (RT_MAX_BOUNCES + 2), ctx->stream);
@@ -190,22 +193,26 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     (void)hipMemsetAsync(q.hit, 0, sizeof(float4) * n, ctx->stream);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ev_init(ctx);
-    *out = ctx;
+    *out = guard.release();
     return RT_OK;
 }
 
-extern "C" int rt_destroy(RtCtx* ctx)
+static void ctx_free(RtCtx* ctx)   // every owned resource; safe on a partially constructed context
 {
-    if (!ctx) return RT_OK;
+    if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_bag(ctx->sceneAllocs); free_bag(ctx->queueAllocs);
     if (ctx->dRayIO) (void)hipFree(ctx->dRayIO);
     if (ctx->dPostF) (void)hipFree(ctx->dPostF);
     if (ctx->dPostB) (void)hipFree(ctx->dPostB);
-    for (auto& e : ctx->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    (void)hipStreamDestroy(ctx->stream);
+    for (auto& e : ctx->evPool) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+extern "C" int rt_destroy(RtCtx* ctx)
+{
+    ctx_free(ctx);
     return RT_OK;
 }
 
@@ -307,6 +314,8 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
     HIPCHK(hipSetDevice(ctx->cfg.device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     free_bag(ctx->sceneAllocs);
+    ctx->sceneLoaded = false; ctx->persist = false; ctx->layout = 0;   // nothing usable until this upload has succeeded
+    ctx->sc = DevScene{};
     DevScene sc{};
     int rc = upload(ctx, &sc.prims, prims, (size_t)nPrims);
     if (rc == RT_OK) rc = upload(ctx, &sc.mats, mats, (size_t)nMats);
