@@ -208,9 +208,17 @@ def cpu_baseline(sa, cam, W, H, accel):
     t0 = time.perf_counter()
     _, _, e, c = o.render(cam, frames, threads=cores)
     t = time.perf_counter() - t0
+    # CPU-B of BASELINE.md §3: the upstream template's trace loop shape (scan-line parallel, one primary ray per pixel, nearest
+    # hit through the BVH, normal visualisation), reported with the reference's own W*H*fps formula
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        o.trace_normals(cam, threads=cores)
+    tb = (time.perf_counter() - t0) / reps
     return {"value": round(W * H * frames / t / 1e6, 4), "unit": "Mrays/s (primary samples/s)", "cores": cores, "kind": "port",
-            "sample": f"{frames} full 1920x1080 frames (1 spp each) of the same scene, {cores} row bands in parallel, {t:.1f} s",
-            "traced_mrays_per_s": round((e["rays"] + c["rays"]) / t / 1e6, 3)}
+            "sample": f"{frames} full {W}x{H} frames (1 spp each) of the same scene, {cores} row bands in parallel, {t:.1f} s",
+            "traced_mrays_per_s": round((e["rays"] + c["rays"]) / t / 1e6, 3),
+            "template_trace_mrays_per_s": round(W * H / tb / 1e6, 3)}
 
 
 if __name__ == "__main__":
