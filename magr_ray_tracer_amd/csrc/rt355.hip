@@ -46,6 +46,7 @@ struct RtCtx {
     int maxDepth2 = 0;
     int layout = 0;   // 0 = traverse the reference arrays as uploaded, 1 = derived pair/triangle-record layout
     bool persist = false;   // persistent-wavefront traversal (layout 1, single BLAS)
+    bool persist4 = false;  // ... over the BVH4
     bool cursorUsed[2 * (RT_MAX_BOUNCES + 2)] = {};   // work-queue heads consumed since the last k_begin_frame
     bool shadeRun[RT_MAX_BOUNCES + 1] = {};           // shade(b) launched since the last k_begin_frame
     bool generated = false;                           // generate launched since the last k_begin_frame
@@ -314,7 +315,7 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
     HIPCHK(hipSetDevice(ctx->cfg.device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     free_bag(ctx->sceneAllocs);
-    ctx->sceneLoaded = false; ctx->persist = false; ctx->layout = 0;   // nothing usable until this upload has succeeded
+    ctx->sceneLoaded = false; ctx->persist = false; ctx->persist4 = false; ctx->layout = 0;   // nothing usable until this upload has succeeded
     ctx->sc = DevScene{};
     DevScene sc{};
     int rc = upload(ctx, &sc.prims, prims, (size_t)nPrims);
@@ -421,10 +422,12 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
     sc.nLights = nLights; sc.nPrims = nPrims; sc.nBlas = nBlas;
     // persistent-wavefront traversal: layout 1 and a TLAS whose root is a leaf (one BLAS)
     ctx->persist = ctx->layout == 1 && ctx->cfg.accel == RT_ACCEL_BVH2 && tlas[0].leftRight == 0 && ctx->cfg.extend_variant != 2;
-    if (ctx->persist) {
+    ctx->persist4 = ctx->layout == 1 && ctx->cfg.accel == RT_ACCEL_BVH4 && tlas[0].leftRight == 0 && ctx->cfg.extend_variant != 2;
+    if (ctx->persist || ctx->persist4) {
         int perCU = 0; hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->cfg.device));
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_persist<false>, kBlock, stack_bytes(ctx)));
+        if (ctx->persist) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_persist<false>, kBlock, stack_bytes(ctx)));
+        else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_persist4<false>, kBlock, stack_bytes(ctx)));
         ctx->persistGrid = std::min(ctx->gridMax, std::max(1, perCU) * prop.multiProcessorCount);
         // the any-hit instantiation needs ~100 SGPRs: the hardware admits one workgroup per CU fewer than the occupancy query reports
         // (MI355X_MICROARCH.md, residency); a surplus workgroup would strand its static first chunk until another one exits
@@ -530,13 +533,15 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
 {
     int rc = need_scene(ctx, "rt_stage_extend"); if (rc) return rc;
     if (bounce < 0 || bounce >= RT_MAX_BOUNCES + 1) return fail(RT_E_INVALID, "rt_stage_extend: bounce %d", bounce);
-    if (ctx->persist) { // a queue head is good for one launch per frame; re-arm it if this stage is run again
+    if (ctx->persist || ctx->persist4) { // a queue head is good for one launch per frame; re-arm it if this stage is run again
         if (ctx->cursorUsed[bounce]) HIPCHK(hipMemsetAsync(ctx->q.cursor + bounce, 0, sizeof(int32_t), ctx->stream));
         ctx->cursorUsed[bounce] = true;
     }
     ev_begin(ctx, ST_EXTEND);
     // bounce 0: primary rays are coherent and finish together, refilling buys nothing -> one ray per lane
-    if (ctx->persist && (bounce > 0 || ctx->cfg.extend_variant == 3))
+    if (ctx->persist4)
+        hipLaunchKernelGGL((k_trace_persist4<false>), bounce > 0 ? dim3(ctx->persistGrid) : grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+    else if (ctx->persist && (bounce > 0 || ctx->cfg.extend_variant == 3))
         hipLaunchKernelGGL((k_trace_persist<false>), dim3(ctx->persistGrid), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
     else if (ctx->persist && ctx->cfg.extend_variant != 5)
         // bounce 0 through the same kernel with one workgroup per 256 rays: its "queue not longer than the grid" branch is the plain
@@ -581,13 +586,15 @@ extern "C" int rt_stage_connect(RtCtx* ctx, int32_t b0, int32_t b1)
     int rc = need_scene(ctx, "rt_stage_connect"); if (rc) return rc;
     if (b0 < 0 || b1 < b0 || b1 >= RT_MAX_BOUNCES) return fail(RT_E_INVALID, "rt_stage_connect: bounce range [%d,%d]", b0, b1);
     const int cap = ctx->nPix * (b1 - b0 + 1);
-    if (ctx->persist) {
+    if (ctx->persist || ctx->persist4) {
         const int ci = (RT_MAX_BOUNCES + 2) + b0;
         if (ctx->cursorUsed[ci]) HIPCHK(hipMemsetAsync(ctx->q.cursor + ci, 0, sizeof(int32_t), ctx->stream));
         ctx->cursorUsed[ci] = true;
     }
     ev_begin(ctx, ST_CONNECT);
-    if (ctx->persist)
+    if (ctx->persist4)
+        hipLaunchKernelGGL((k_trace_persist4<true>), dim3(ctx->persistGridConnect), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1, 0, ctx->tune);
+    else if (ctx->persist)
         hipLaunchKernelGGL((k_trace_persist<true>), dim3(ctx->persistGridConnect), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1, 0, ctx->tune);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4 && ctx->layout == 1)
         hipLaunchKernelGGL((k_connect<RT_ACCEL_BVH4, 1>), grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);

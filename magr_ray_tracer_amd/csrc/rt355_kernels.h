@@ -687,6 +687,139 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
     flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
 }
 
+// ------------------------------------------------------------------ k_trace_persist4: persistent wavefronts over the BVH4 (layout 1, one BLAS)
+// Same work distribution as k_trace_persist.  A lane is either on a NODE event (fetch the 128-byte quad record, four slab tests
+// with the ray->t of node entry, push the interior children that were hit in slot order, remember the hit leaf children) or on a
+// LEAF event (one triangle of the lowest pending leaf child).  The reference interleaves pushes and leaf tests in slot order
+// (bvh.cl:78-92), but a push depends only on the distances taken at node entry, never on the shrinking ray->t, so doing the pushes
+// first leaves the stack contents, the order of triangle tests, `steps` and the counters unchanged.
+template <bool OCC>
+__global__ __launch_bounds__(kBlock) void k_trace_persist4(DevScene sc, DevQueues q, int b0, int b1, int renderBVH, PersistTune tune)
+{
+    const int kChunk = tune.chunk, kRefill = tune.refill, kInner = tune.inner, kLeafK = tune.leafK;
+    extern __shared__ uint32_t stk[];
+    const int lane = threadIdx.x & 63;
+    const int qFirst = OCC ? q.nShadow[b0] : 0;
+    const int n = OCC ? q.nShadow[b1 + 1] - qFirst : q.nRays[b0];
+    int32_t* cursor = q.cursor + (OCC ? (RT_MAX_BOUNCES + 2) + b0 : b0);
+    const RtBVHInstance* inst = sc.blas + sc.tlas[0].BLASidx;
+    const uint32_t rootNode = inst->bvhIdx;
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = inst->invT[k];
+
+    WorkCtr wc = { 0, 0, 0, 0 };
+    uint32_t rays = 0;
+    TRay r; r.t = 0; r.prim = -1; r.u = r.v = 0; r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.rx = r.ry = r.rz = 0;
+    uint32_t cur = 0, sp = 0, leafMask = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+    int slot = -1, steps = 0;
+    float tLight = 0;
+    const int nWaves = gridDim.x * (kBlock / 64), waveId = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+
+    auto setup = [&](int idx) {
+        float4 O, D; float tmax;
+        if (OCC) { const float4 a = q.sA[qFirst + idx], b = q.sB[qFirst + idx]; O = a; D = b; tmax = a.w; }
+        else { O = q.O[b0 & 1][idx]; D = q.D[b0 & 1][idx]; tmax = kFar; }
+        const float4 Dv = mk4(D.x, D.y, D.z, 0.0f), Ov = mk4(O.x, O.y, O.z, 0.0f);
+        r.dx = dot3(mk4(T[0], T[1], T[2], 0), Dv); r.dy = dot3(mk4(T[4], T[5], T[6], 0), Dv); r.dz = dot3(mk4(T[8], T[9], T[10], 0), Dv);
+        r.ox = dot3(mk4(T[0], T[1], T[2], 0), Ov) + T[3]; r.oy = dot3(mk4(T[4], T[5], T[6], 0), Ov) + T[7];
+        r.oz = dot3(mk4(T[8], T[9], T[10], 0), Ov) + T[11];
+        r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
+        r.t = tmax; r.prim = -1; r.u = 0.0f; r.v = 0.0f;
+        tLight = tmax;
+    };
+    auto finish = [&](int idx, int st, bool occluded) {
+        if (OCC) { if (occluded) q.sC[qFirst + idx] = splat(0.0f); }
+        else {
+            q.hit[idx] = mk4(r.t, __int_as_float(r.prim), r.u, r.v);
+            if (q.steps) q.steps[idx] = st;
+            if (renderBVH) q.accum[q.firstPixel + idx] = splat((float)(uint32_t)st / 255.f);
+        }
+    };
+
+    if (n <= nWaves * 64) {   // short queue: plain one-ray-per-lane loop
+        const int idx = waveId * 64 + lane;
+        if (idx < n) {
+            setup(idx);
+            rays = 1; wc.inst = 1;
+            const int st = traverse_bvh4_packed<OCC>(sc, r, rootNode, stk, wc);
+            finish(idx, st, st == -1);
+        }
+        flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
+        return;
+    }
+    int chunkNext = min(waveId * kChunk, n), chunkEnd = min(waveId * kChunk + kChunk, n);
+    bool exhausted = false;
+
+    for (;;) {
+        const unsigned long long idleMask = __ballot(slot < 0);
+        const int nIdle = __popcll(idleMask);
+        if (nIdle == 64 && exhausted && chunkNext >= chunkEnd) break;
+        if (nIdle >= kRefill && !(exhausted && chunkNext >= chunkEnd)) {
+            if (chunkNext >= chunkEnd) {
+                int c = 0;
+                if (lane == 0) c = atomicAdd(cursor, kChunk);
+                c = __shfl(c, 0, 64) + nWaves * kChunk;
+                chunkNext = c; chunkEnd = min(c + kChunk, n);
+                if (c >= n) { exhausted = true; chunkNext = chunkEnd = 0; }
+            }
+            if (chunkNext < chunkEnd) {
+                const int rank = __popcll(idleMask & ((1ull << lane) - 1ull));
+                const int idx = chunkNext + rank;
+                if (slot < 0 && idx < chunkEnd) {
+                    setup(idx);
+                    cur = rootNode; sp = 0; steps = 0; leafMask = 0; slot = idx;
+                    rays++; wc.inst++;
+                }
+                chunkNext = min(chunkNext + nIdle, chunkEnd);
+            }
+        }
+#pragma unroll 1
+        for (int it = 0; it < kInner; it++) {
+            const bool act = slot >= 0, atLeaf = act && leafMask != 0u;
+            const unsigned long long lm = __ballot(atLeaf), im = __ballot(act && !atLeaf);
+            if ((lm | im) == 0ull) break;
+            const bool doLeaf = im == 0ull || __popcll(lm) >= kLeafK;
+            bool done = false, occluded = false;
+            if (doLeaf) {
+                if (atLeaf) {
+                    const int k = __ffs((int)leafMask) - 1;
+                    uint32_t ek = k == 0 ? e0 : (k == 1 ? e1 : (k == 2 ? e2 : e3));
+                    const uint32_t first = ek & 0x00ffffffu, count = (ek >> 24) & 0x7fu;
+                    wc.prim++;
+                    test_tri_packed(sc, first, r);
+                    if (OCC && r.t < tLight) { done = true; occluded = true; }
+                    else if (count > 1) {
+                        ek = kLeafBit | ((count - 1) << 24) | (first + 1);
+                        if (k == 0) e0 = ek; else if (k == 1) e1 = ek; else if (k == 2) e2 = ek; else e3 = ek;
+                    } else {
+                        leafMask &= leafMask - 1u;
+                        if (leafMask == 0u) { if (sp == 0) done = true; else cur = STK(--sp); }
+                    }
+                }
+            } else if (act && !atLeaf) {
+                steps++; wc.node++;
+                const float4* p = sc.quads + (size_t)cur * 8;
+                const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5], q6 = p[6];
+                e0 = __float_as_uint(q6.x); e1 = __float_as_uint(q6.y); e2 = __float_as_uint(q6.z); e3 = __float_as_uint(q6.w);
+                const float d0 = e0 != kNoChild ? slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f)) : kFar;
+                const float d1 = e1 != kNoChild ? slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f)) : kFar;
+                const float d2 = e2 != kNoChild ? slab(r, mk4(q3.x, q3.y, q3.z, 0.0f), mk4(q3.w, q4.x, q4.y, 0.0f)) : kFar;
+                const float d3 = e3 != kNoChild ? slab(r, mk4(q4.z, q4.w, q5.x, 0.0f), mk4(q5.y, q5.z, q5.w, 0.0f)) : kFar;
+                uint32_t m = 0;
+                if (e0 != kNoChild && d0 < tLight) { if (e0 & kLeafBit) m |= 1u; else { STK(sp) = e0; sp++; } }
+                if (e1 != kNoChild && d1 < tLight) { if (e1 & kLeafBit) m |= 2u; else { STK(sp) = e1; sp++; } }
+                if (e2 != kNoChild && d2 < tLight) { if (e2 & kLeafBit) m |= 4u; else { STK(sp) = e2; sp++; } }
+                if (e3 != kNoChild && d3 < tLight) { if (e3 & kLeafBit) m |= 8u; else { STK(sp) = e3; sp++; } }
+                leafMask = m;
+                if (m == 0u) { if (sp == 0) done = true; else cur = STK(--sp); }
+            }
+            if (done) { finish(slot, steps, occluded); slot = -1; leafMask = 0; }
+        }
+    }
+    flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
+}
+
 // ------------------------------------------------------------------ shading helpers
 struct SRay { // the reference Ray fields shade() reads and writes
     float4 O, D, N, I, inten;

@@ -548,3 +548,33 @@ def test_instance_transform_non_identity_bit_exact():
         assert_bits(d.read_accum(), acc, f"rotated instance, accel={accel}")
         _ctr_equal(d.counters(), e, c)
         d.close()
+
+
+@pytest.mark.parametrize("accel", [0, 1])
+def test_persistent_wavefronts_vs_oracle(accel, monkeypatch):
+    """The persistent-wavefront kernels (k_trace_persist / k_trace_persist4) only take over when a queue is longer than one ray per
+    resident lane; one workgroup per CU (RT355_TUNE's fifth field) brings that threshold down to 65,536 rays so that a 640x360 frame
+    runs every bounce >= 1 and every connect launch through the refill/event machine.  Accumulator, RNG state, counters and the
+    per-pixel `steps` heat map must match the oracle bit for bit, and the one-ray-per-lane variant of the same layout."""
+    monkeypatch.setenv("RT355_TUNE", "64,20,6,8,1")
+    Wd, Hd = 640, 360
+    v = dict(DEFAULT, accel=accel)
+    s, view = scenes.sponza_class(0.5)
+    sa = s.arrays()
+    cam = scenes.camera_for(view, Wd, Hd)
+    o = Oracle(sa, Wd, Hd, **v)
+    ref, seeds, e, c = o.render(cam, 2)
+    out = []
+    for variant in (0, 2):
+        d = Device(Wd, Hd, extend_variant=variant, **v)
+        d.upload(sa)
+        d.seed_default()
+        d.enable_steps(True)
+        d.render(cam, 2)
+        out.append((d.read_accum(), d.get_seeds(), d.counters(), d.get_steps()))
+        d.close()
+    assert_bits(out[0][0], ref, "persistent wavefronts vs oracle")
+    assert np.array_equal(out[0][1], seeds)
+    _ctr_equal(out[0][2], e, c)
+    assert out[0][2]["extend_rays"] > 3 * 65536          # the long-queue branch really ran
+    assert bits_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][3], out[1][3])

@@ -19,7 +19,7 @@ cam = scenes.camera_for(view, W, H)
 ref = None
 for rep in range(2):
     for v in variants:
-        for accel in (0,):
+        for accel in (int(os.environ.get("AB_ACCEL", "0")),):
             d = Device(W, H, accel=accel, profile=True, extend_variant=v)
             d.upload(sa)
             cam["focalLength"] = d.focus(W // 2, H // 2, cam)
