@@ -40,5 +40,5 @@ for rep in range(2):
             B = c["extend_rays"] * 48 + c["extend_inst_visits"] * 68 + c["extend_node_visits"] * 96 + c["extend_prim_tests"] * 52
             print(f"variant {v} accel {accel}: {dt / frames * 1e3:.3f} ms/frame  " +
                   "  ".join(f"{k[:-3]} {st[k] / frames:.3f}" for k in st if k.endswith("_ms")) +
-                  f"  extend {B / (st['extend_ms'] * 1e-3) / 1e9:.0f} GB/s  bit-equal-to-first {same}", flush=True)
+                  f"  extend {B / (st['extend_ms'] * 1e-3) / 1e9:.0f} GB/s  bit-equal-to-first {same} crc {int(a.view(np.uint32).astype(np.uint64).sum())}", flush=True)
             d.close()
