@@ -578,7 +578,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
     if (n <= nWaves * 64) {
         // Short queue (late bounces): every wave gets at most one 64-ray chunk and nothing is left to refill from, so
         // run the plain one-ray-per-lane loop, which has less per-step overhead than the refill state machine.
-        const int idx = waveId * 64 + lane;
+        int idx = waveId * 64 + lane;
+        if (!OCC && b0 == 0 && ((q.width | (q.nPix / q.width)) & 7) == 0) {
+            // primary rays: a wave takes an 8x8 pixel tile instead of a 64x1 strip (the queue of bounce 0 is the pixel grid)
+            const int tilesX = q.width >> 3, ty = waveId / tilesX, tx = waveId - ty * tilesX;
+            idx = ((ty << 3) + (lane >> 3)) * q.width + (tx << 3) + (lane & 7);
+        }
         if (idx < n) {
             float4 O, D; float tmax;
             if (OCC) { const float4 a = q.sA[qFirst + idx], b = q.sB[qFirst + idx]; O = a; D = b; tmax = a.w; }
@@ -738,7 +743,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist4(DevScene sc, DevQueue
     };
 
     if (n <= nWaves * 64) {   // short queue: plain one-ray-per-lane loop
-        const int idx = waveId * 64 + lane;
+        int idx = waveId * 64 + lane;
+        if (!OCC && b0 == 0 && ((q.width | (q.nPix / q.width)) & 7) == 0) {   // primary rays: 8x8 pixel tile per wave
+            const int tilesX = q.width >> 3, ty = waveId / tilesX, tx = waveId - ty * tilesX;
+            idx = ((ty << 3) + (lane >> 3)) * q.width + (tx << 3) + (lane & 7);
+        }
         if (idx < n) {
             setup(idx);
             rays = 1; wc.inst = 1;

@@ -1,0 +1,113 @@
+// gather_probe: does a cooperative (quad-coalesced) fetch of per-lane 64-byte records beat four 16-byte loads per lane on MI355X?
+// Mimics the node event of k_trace_persist: a dependent chain of random 64-B record fetches out of a 32 MB table, ~50 VALU ops per step.
+//   A: lane l issues 4 x global_load_dwordx4 at its own record (what the kernels do today; 4 x 64 line requests per wave step)
+//   B: in load j, lane l fetches chunk (l & 3) of the record wanted by lane j*16 + (l >> 2); the quad's 64 B are contiguous, so the
+//      texture addresser sees 16 line requests per load; the chunks go through a 4 KB/wave LDS transposition back to their owners.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/gather_probe.hip -o gpurun_out/gather_probe ; run: gather_probe [extraLdsKB]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __forceinline__ float work(float4 q0, float4 q1, float4 q2, float ox, float oy, float oz, float rx, float ry, float rz)
+{
+    // two slab tests, same op mix as the traversal step
+    float a0 = (q0.x - ox) * rx, a1 = (q0.w - ox) * rx, b0 = (q0.y - oy) * ry, b1 = (q1.x - oy) * ry, c0 = (q0.z - oz) * rz, c1 = (q1.y - oz) * rz;
+    float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1)), tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+    float d0 = (q1.z - ox) * rx, d1 = (q2.y - ox) * rx, e0 = (q1.w - oy) * ry, e1 = (q2.z - oy) * ry, f0 = (q2.x - oz) * rz, f1 = (q2.w - oz) * rz;
+    float un = fmaxf(fmaxf(fminf(d0, d1), fminf(e0, e1)), fminf(f0, f1)), uf = fminf(fminf(fmaxf(d0, d1), fmaxf(e0, e1)), fmaxf(f0, f1));
+    return (tf >= tn ? tn : 1e30f) - (uf >= un ? un : 1e30f);
+}
+
+__global__ __launch_bounds__(256) void gatherA(const float4* __restrict__ tab, int steps, float* out, uint32_t mask)
+{
+    extern __shared__ uint32_t pad[];
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    uint32_t idx = ((uint32_t)gid * 2654435761u >> 13) & mask;
+    float acc = 0, ox = gid * 1e-6f, oy = 0.5f, oz = 0.25f, rx = 1.5f, ry = -0.7f, rz = 0.9f;
+    for (int s = 0; s < steps; s++) {
+        const float4* p = tab + (size_t)idx * 4;
+        const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        const float w = work(q0, q1, q2, ox, oy, oz, rx, ry, rz);
+        acc += w;
+        idx = w > 0.0f ? __float_as_uint(q3.x) : __float_as_uint(q3.y);
+    }
+    out[gid] = acc + (float)pad[0] * 0.0f;
+}
+
+__global__ __launch_bounds__(256) void gatherB(const float4* __restrict__ tab, int steps, float* out, uint32_t mask)
+{
+    extern __shared__ float4 xb[];   // [wave][chunk][lane]
+    const int gid = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4* x = xb + wave * 256;
+    uint32_t idx = ((uint32_t)gid * 2654435761u >> 13) & mask;
+    float acc = 0, ox = gid * 1e-6f, oy = 0.5f, oz = 0.25f, rx = 1.5f, ry = -0.7f, rz = 0.9f;
+    const int g = lane >> 2, c = lane & 3;
+    for (int s = 0; s < steps; s++) {
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t ni = (uint32_t)__shfl((int)idx, j * 16 + g, 64);
+            v[j] = tab[(size_t)ni * 4 + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[c * 64 + j * 16 + g] = v[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float4 q0 = x[lane], q1 = x[64 + lane], q2 = x[128 + lane], q3 = x[192 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float w = work(q0, q1, q2, ox, oy, oz, rx, ry, rz);
+        acc += w;
+        idx = w > 0.0f ? __float_as_uint(q3.x) : __float_as_uint(q3.y);
+    }
+    out[gid] = acc;
+}
+
+int main(int argc, char** argv)
+{
+    const int nrec = 1 << (argc > 1 ? atoi(argv[1]) : 19), steps = 64;   // table = nrec * 64 B
+    printf("table %d records = %.2f MB\n", nrec, nrec * 64.0 / 1048576.0);
+    std::vector<float> h((size_t)nrec * 16);
+    uint32_t s = 12345u;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; };
+    for (int i = 0; i < nrec; i++) {
+        float* r = &h[(size_t)i * 16];
+        for (int k = 0; k < 12; k++) r[k] = (float)(rnd() & 0xffff) / 65536.0f;
+        uint32_t a = rnd() & (nrec - 1), b = rnd() & (nrec - 1);
+        memcpy(&r[12], &a, 4); memcpy(&r[13], &b, 4); r[14] = r[15] = 0;
+    }
+    float4* tab; float* out;
+    const int maxThreads = 256 * 256 * 8;
+    CHK(hipMalloc(&tab, h.size() * 4)); CHK(hipMalloc(&out, (size_t)maxThreads * 4));
+    CHK(hipMemcpy(tab, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    std::vector<float> ra(maxThreads), rb(maxThreads);
+    for (int perCU = 4; perCU <= 8; perCU += 3) {
+        // LDS per block chosen so that exactly perCU blocks fit a CU (160 KB), like the traversal stack does
+        const size_t lds = (size_t)(160 * 1024 / perCU) & ~(size_t)1023;
+        if (lds > 64 * 1024) continue;
+        const int blocks = 256 * perCU, total = blocks * 256;
+        for (int which = 0; which < 2; which++) {
+            if (which == 1 && lds < 16 * 1024) continue;
+            float best = 1e9f;
+            for (int rep = 0; rep < 5; rep++) {
+                CHK(hipEventRecord(e0));
+                if (which == 0) hipLaunchKernelGGL(gatherA, dim3(blocks), dim3(256), lds, 0, tab, steps, out, (uint32_t)(nrec - 1));
+                else hipLaunchKernelGGL(gatherB, dim3(blocks), dim3(256), lds, 0, tab, steps, out, (uint32_t)(nrec - 1));
+                CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+            }
+            CHK(hipMemcpy(which ? rb.data() : ra.data(), out, (size_t)total * 4, hipMemcpyDeviceToHost));
+            printf("%s blocks/CU %d (lds %zu KB): %.3f ms, %.2f G records/s\n", which ? "B coop" : "A 4xld", perCU, lds >> 10, best,
+                   (double)total * steps / best / 1e6);
+        }
+        int bad = 0;
+        if (lds >= 16 * 1024) for (int i = 0; i < total; i++) if (ra[i] != rb[i]) bad++;
+        printf("   mismatches A vs B: %d\n", bad);
+    }
+    return 0;
+}

@@ -1,22 +1,29 @@
-"""Per-bounce kernel durations from a rocprofv3 kernel-trace CSV (dispatch order = bounce order)."""
-import csv, sys, collections
+"""Per-bounce kernel durations from a rocprofv3 kernel-trace CSV (dispatch order = bounce order within a frame)."""
+import collections
+import csv
+import sys
+
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-seq = collections.defaultdict(list)
+frames, cur = [], None
 for r in rows:
     n = r["Kernel_Name"]
-    if "k_extend" in n or "k_trace_persist<false>" in n:
-        key = "extend:" + n.split("rt355dev::")[1].split("(")[0]
-    elif "k_connect" in n or "k_trace_persist<true>" in n:
-        key = "connect:" + n.split("rt355dev::")[1].split("(")[0]
-    else:
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    if "k_generate" in n:
+        cur = collections.defaultdict(list)
+        frames.append(cur)
+    if cur is None:
         continue
-    seq[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-for k, v in seq.items():
-    if k.startswith("extend"):
-        per = [[] for _ in range(7)]
-        for i, d in enumerate(v):
-            per[i % 7].append(d)
-        print(k, "launches", len(v), "per-bounce median us:", [round(sorted(p)[len(p) // 2], 1) for p in per if p], "sum", round(sum(sorted(p)[len(p) // 2] for p in per if p), 1))
-    else:
-        print(k, "launches", len(v), "median us", round(sorted(v)[len(v) // 2], 1))
+    for key, pat in (("extend", ("k_extend", "k_trace_persist<false>", "k_trace_persist4<false>", "k_trace_mixed")), ("shade", ("k_shade",)),
+                     ("connect", ("k_connect", "k_trace_persist<true>", "k_trace_persist4<true>")), ("accumulate", ("k_accumulate",)),
+                     ("generate", ("k_generate",))):
+        if any(p in n for p in pat):
+            cur[key].append(d)
+frames = [f for f in frames if len(f["extend"]) == len(frames[len(frames) // 2]["extend"])]
+for key in ("generate", "extend", "shade", "connect", "accumulate"):
+    m = max(len(f[key]) for f in frames)
+    med = []
+    for i in range(m):
+        v = sorted(f[key][i] for f in frames if len(f[key]) > i)
+        med.append(round(v[len(v) // 2], 1))
+    print(f"{key:10s} frames {len(frames)} per-launch median us {med}  sum {round(sum(med), 1)}")
