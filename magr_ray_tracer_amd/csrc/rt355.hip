@@ -16,6 +16,8 @@
 
 using namespace rt355dev;
 
+// workgroups of 256 threads the hardware admits per CU whatever the occupancy query says: any kernel / kernels with <= 96 SGPRs
+static constexpr int kAdmitAnySgpr = 6, kAdmit96Sgpr = 7;
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...)
 {
@@ -150,14 +152,16 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     ctx->gridMax = (ctx->nPix * std::max(1, c.max_bounces) + kBlock - 1) / kBlock; // connect may cover max_bounces*nPix shadow rays
     ctx->gridMax = std::max(ctx->gridMax, 4096);                                    // and the persistent grid (<= 256 CUs x 8 blocks)
     ctx->var = DevVariant{ c.shading, c.sampling, c.accel, c.russian_roulette ? 1 : 0, c.filter_fireflies ? 1 : 0, c.max_bounces };
-    {   // k_shade's grid must be co-resident.  The occupancy query can over-report by one workgroup per CU for
-        // SGPR-heavy 256-thread kernels on this chip (MI355X_MICROARCH.md, residency), so launch one fewer per CU.
+    {   // k_shade's grid must be co-resident.  The occupancy query knows the VGPR, LDS and wave-slot limits but not the SGPR file:
+        // 256-thread workgroups are admitted up to min(query, 8, 800 / (ceil16(sgprs) + 16)) per CU (MI355X_MICROARCH.md, residency),
+        // which is 6 for any kernel (<= 112 SGPRs) and 7 up to 96 SGPRs.  k_shade is held to 4 by its registers and 39 KB of LDS.
         hipDeviceProp_t prop; int perCU = 0;
         HIPCHK(hipGetDeviceProperties(&prop, c.device));
         if (c.shading == RT_SHADING_NEE) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<true>, kBlock, 0));
         else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<false>, kBlock, 0));
-        ctx->shadeGrid = prop.multiProcessorCount * std::max(1, perCU - 1);
-        if (const char* g = getenv("RT355_SHADE_PER_CU")) { int v = atoi(g); if (v > 0 && v <= std::max(1, perCU - 1)) ctx->shadeGrid = prop.multiProcessorCount * v; }
+        perCU = std::min(perCU, kAdmitAnySgpr);
+        ctx->shadeGrid = prop.multiProcessorCount * std::max(1, perCU);
+        if (const char* g = getenv("RT355_SHADE_PER_CU")) { int v = atoi(g); if (v > 0 && v <= std::max(1, perCU)) ctx->shadeGrid = prop.multiProcessorCount * v; }
     }
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(RT_E_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -167,7 +171,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     auto& bag = ctx->queueAllocs;
 #define QA(field, count) if (rc == RT_OK) rc = dalloc(bag, &q.field, count)
     const size_t nTiles = (n + kBlock - 1) / kBlock;
-    for (int k = 0; k < 2; k++) { QA(O[k], n); QA(D[k], n); QA(inten[k], n); QA(meta[k], n); QA(tile[k], nTiles + 2); QA(super[k], nTiles / 64 + 2); }
+    for (int k = 0; k < 2; k++) { QA(O[k], n); QA(D[k], n); QA(inten[k], n); QA(meta[k], n); QA(tile[k], nTiles + 2); QA(super[k], nTiles / 64 + 2); QA(supAcc[k], nTiles / 64 + 2); }
     QA(hit, n);
     QA(sA, nS); QA(sB, nS); QA(sC, nS);
     QA(nRays, RT_MAX_BOUNCES + 2); QA(nShadow, RT_MAX_BOUNCES + 2); QA(cursor, 2 * (RT_MAX_BOUNCES + 2)); QA(fault, 1);
@@ -190,6 +194,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     for (int k = 0; k < 2; k++) {
         (void)hipMemsetAsync(q.tile[k], 0, sizeof(unsigned long long) * (nTiles + 2), ctx->stream);
         (void)hipMemsetAsync(q.super[k], 0, sizeof(unsigned long long) * (nTiles / 64 + 2), ctx->stream);
+        (void)hipMemsetAsync(q.supAcc[k], 0, sizeof(unsigned long long) * (nTiles / 64 + 2), ctx->stream);
     }
     (void)hipMemsetAsync(q.hit, 0, sizeof(float4) * n, ctx->stream);
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -428,10 +433,10 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         HIPCHK(hipGetDeviceProperties(&prop, ctx->cfg.device));
         if (ctx->persist) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_persist<false>, kBlock, stack_bytes(ctx)));
         else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_persist4<false>, kBlock, stack_bytes(ctx)));
-        ctx->persistGrid = std::min(ctx->gridMax, std::max(1, perCU) * prop.multiProcessorCount);
-        // the any-hit instantiation needs ~100 SGPRs: the hardware admits one workgroup per CU fewer than the occupancy query reports
-        // (MI355X_MICROARCH.md, residency); a surplus workgroup would strand its static first chunk until another one exits
-        ctx->persistGridConnect = std::min(ctx->gridMax, std::max(1, perCU - 1) * prop.multiProcessorCount);
+        // the closest-hit instantiations use ~90 SGPRs, the any-hit ones ~100: the hardware admits 7 resp. 6 workgroups per CU where
+        // the occupancy query may say more (see rt_create); a surplus workgroup would strand its static first chunk until another exits
+        ctx->persistGrid = std::min(ctx->gridMax, std::max(1, std::min(perCU, kAdmit96Sgpr)) * prop.multiProcessorCount);
+        ctx->persistGridConnect = std::min(ctx->gridMax, std::max(1, std::min(perCU, kAdmitAnySgpr)) * prop.multiProcessorCount);
         if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner,leafK[,blocksPerCU]" (tuning aid)
             int a = 0, b = 0, c = 0, l = 0, d = 0;
             int k = sscanf(t, "%d,%d,%d,%d,%d", &a, &b, &c, &l, &d);
@@ -569,6 +574,7 @@ extern "C" int rt_stage_shade(RtCtx* ctx, int32_t bounce)
         const size_t nTiles = ((size_t)ctx->nPix + kBlock - 1) / kBlock;
         HIPCHK(hipMemsetAsync(ctx->q.tile[bounce & 1], 0, sizeof(unsigned long long) * (nTiles + 2), ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->q.super[bounce & 1], 0, sizeof(unsigned long long) * (nTiles / 64 + 2), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->q.supAcc[bounce & 1], 0, sizeof(unsigned long long) * (nTiles / 64 + 2), ctx->stream));
     }
     ev_begin(ctx, ST_SHADE);
     const dim3 sg((unsigned)std::max(1, std::min(ctx->shadeGrid, (ctx->nPix + kBlock - 1) / kBlock)));

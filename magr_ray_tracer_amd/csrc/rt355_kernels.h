@@ -64,6 +64,7 @@ struct DevQueues {
     // single-pass scan state of k_shade, one set per bounce parity: [1 + t] = status of tile t
     unsigned long long* tile[2];
     unsigned long long* super[2];   // [s] = status of super-tile s (64 consecutive tiles), same encoding
+    unsigned long long* supAcc[2];  // [s] = running total of super-tile s: [63:40] tiles arrived, [39:20] extension rays, [19:0] shadow rays
     int32_t* nRays;    // [RT_MAX_BOUNCES+2]  rays entering bounce b
     int32_t* nShadow;  // [RT_MAX_BOUNCES+2]  shadow rays of bounce b occupy [nShadow[b], nShadow[b+1])
     int32_t* fault;    // [1] set to 1 by a kernel whose bounded wait expired (host turns it into RT_E_DEVICE)
@@ -503,7 +504,7 @@ RT_FORCEINLINE void primary_ray(const RtCamera& cam, int x, int y, int W, int H,
 __global__ __launch_bounds__(kBlock) void k_generate(DevQueues q, RtCamera cam, int aa)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (threadIdx.x == 0) { q.tile[0][1 + blockIdx.x] = 0ull; if ((blockIdx.x & 63) == 0) q.super[0][blockIdx.x >> 6] = 0ull; }   // arm shade(0)'s scan
+    if (threadIdx.x == 0) { q.tile[0][1 + blockIdx.x] = 0ull; if ((blockIdx.x & 63) == 0) { q.super[0][blockIdx.x >> 6] = 0ull; q.supAcc[0][blockIdx.x >> 6] = 0ull; } }   // arm shade(0)'s scan
     if (i >= q.nPix) return;
     const int idx = q.firstPixel + i;
     uint32_t seed = q.seeds[i];
@@ -1022,11 +1023,11 @@ RT_FORCEINLINE uint32_t tile_ext(unsigned long long v) { return (uint32_t)((v >>
 RT_FORCEINLINE uint32_t tile_sh(unsigned long long v) { return (uint32_t)(v & 0x7fffffffull); }
 
 // Persistent workgroups, static round-robin tiles: workgroup g shades tiles g, g+G, g+2G, ... in increasing
-// order (tile = 256 consecutive queue slots).  A tile's look-back only waits for tiles with smaller ids, and
-// those belong to workgroups of the same launch that process their own tiles in increasing order, so by
-// induction over the tile id every wait ends as long as the G workgroups can be co-resident — the host launches
-// G <= 4 per CU, half of what this kernel's registers/LDS admit, and uses no ticket atomics (8,100 tickets on
-// one word cost ~90 us per launch on this chip, more than the shading itself).
+// order (tile = 256 consecutive queue slots).  Publishing a tile's counts waits for nothing; closing a super-tile and
+// resolving a tile's position only wait for words of smaller tile / super-tile ids, and those belong to workgroups of the
+// same launch that process their own tiles in increasing order, so by induction over the id every wait ends as long as the
+// G workgroups are co-resident - the host launches what the hardware admits per CU (4: registers and LDS; see rt_create)
+// and uses no ticket atomics (8,100 tickets on one word cost ~90 us per launch on this chip, more than the shading itself).
 // Bounded wait on a status word: every spin in this library has an upper bound (~seconds), after which the kernel raises
 // q.fault and carries on with a zero payload instead of hanging the GPU; the host reports RT_E_DEVICE.
 static constexpr uint32_t kSpinLimit = 1u << 22;   // x ~1-2 us per poll: several seconds
@@ -1035,7 +1036,8 @@ RT_FORCEINLINE unsigned long long wait_word(const unsigned long long* p, unsigne
     unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t spins = 0;
     while (needFlag == 2ull ? (v >> 62) != 2ull : (v >> 62) == 0ull) {
-        if (++spins > kSpinLimit) { *fault = 1; return kTilePrefixZero; }
+        // give up when the bound is reached - or when another wave already has: once the flag is up the launch's results are void
+        if (++spins > kSpinLimit || ((spins & 1023u) == 0u && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { *fault = 1; return kTilePrefixZero; }
         // back off: a few quick polls, then ~1 us naps, so that thousands of waiting waves do not flood the L2 with polls
         if (spins < 4) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
         v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1044,12 +1046,13 @@ RT_FORCEINLINE unsigned long long wait_word(const unsigned long long* p, unsigne
 }
 
 template <bool NEE>
-__global__ __launch_bounds__(kBlock, 5) void k_shade(DevScene sc, DevQueues q, DevVariant var, int bounce)
+__global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, DevVariant var, int bounce)
 {
-    __shared__ uint32_t sWaveE[kBlock / 64], sWaveS[kBlock / 64], sBaseE, sBaseS;
+    // [2]: a tile's outputs are written one tile late (see the loop), so the counts and the shadow records of two tiles are alive
+    __shared__ uint32_t sWaveE[2][kBlock / 64], sWaveS[2][kBlock / 64], sBaseE, sBaseS;
     // Survivors wait in LDS (104 B per lane) while the ordered scan resolves, instead of in ~28 registers: the
     // kernel's occupancy is set by the shading code, not by values that are merely parked across the scan.
-    __shared__ float4 sExtO[kBlock], sExtD[kBlock], sExtI[kBlock], sShA[kBlock], sShB[kBlock], sShC[kBlock];
+    __shared__ float4 sExtO[kBlock], sExtD[kBlock], sExtI[kBlock], sShA[2][kBlock], sShB[2][kBlock], sShC[2][kBlock];
     __shared__ uint2 sExtM[kBlock];
     const int cur = bounce & 1, nxt = cur ^ 1;
     unsigned long long* state = q.tile[cur];
@@ -1063,14 +1066,69 @@ __global__ __launch_bounds__(kBlock, 5) void k_shade(DevScene sc, DevQueues q, D
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int shadowBase = q.nShadow[bounce];
 
-    for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+    // Resolve the ordered scan for tile `t` (its counts are in sWave*[pp], its aggregate has been published) and write its
+    // survivors to their final queue positions.  Called by the whole workgroup.
+    auto drain = [&](uint32_t t, int pp, unsigned long long em, unsigned long long sm, bool extValid, bool shValid) {
+        if (wave == 0) {
+            uint32_t aggE = 0, aggS = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; w++) { aggE += sWaveE[pp][w]; aggS += sWaveS[pp][w]; }
+            // Level 1 of the ordered scan: the counts of the earlier tiles of the own super-tile (one 64-lane read) plus the
+            // inclusive prefix of the previous super-tile (level 2, resolved by whichever workgroup closed that super-tile).
+            const uint32_t sup = t >> 6, inSup = t & 63u;
+            // lanes 0..inSup-1 fetch the earlier tiles' words, lane 63 the previous super-tile's: one round trip for both levels
+            unsigned long long v = 0ull;
+            if ((uint32_t)lane < inSup) v = wait_word(&state[1 + (sup << 6) + (uint32_t)lane], 0ull, q.fault);
+            else if (lane == 63 && sup > 0) v = wait_word(&super[cur][sup - 1], 2ull, q.fault);
+            const unsigned long long vp = __shfl(v, 63, 64);
+            const uint32_t preE = sup > 0 ? tile_ext(vp) : 0u, preS = sup > 0 ? tile_sh(vp) : 0u;   // inclusive prefix of super-tiles [0, sup)
+            uint32_t inE = (uint32_t)lane < inSup ? tile_ext(v) : 0u, inS = (uint32_t)lane < inSup ? tile_sh(v) : 0u;   // counts of tiles [64*sup, t)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { inE += __shfl_xor(inE, off, 64); inS += __shfl_xor(inS, off, 64); }
+            if (lane == 0) {
+                sBaseE = preE + inE; sBaseS = preS + inS;
+                if (t == numTiles - 1) { q.nRays[bounce + 1] = (int)(preE + inE + aggE); q.nShadow[bounce + 1] = shadowBase + (int)(preS + inS + aggS); }
+            }
+        }
+        __syncthreads();
+        uint32_t baseE = sBaseE, baseS = sBaseS + (uint32_t)shadowBase;
+        for (int w = 0; w < wave; w++) { baseE += sWaveE[pp][w]; baseS += sWaveS[pp][w]; }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (extValid) {
+            const uint32_t dst = baseE + (uint32_t)__popcll(em & below);
+            q.O[nxt][dst] = sExtO[threadIdx.x]; q.D[nxt][dst] = sExtD[threadIdx.x]; q.inten[nxt][dst] = sExtI[threadIdx.x];
+            q.meta[nxt][dst] = sExtM[threadIdx.x];
+        }
+        if (shValid) {
+            const uint32_t dst = baseS + (uint32_t)__popcll(sm & below);
+            q.sA[dst] = sShA[pp][threadIdx.x]; q.sB[dst] = sShB[pp][threadIdx.x]; q.sC[dst] = sShC[pp][threadIdx.x];
+        }
+        __syncthreads();   // sExt*, sBase* and sSh*[pp] are free again
+    };
+
+    // Software pipeline over this workgroup's tiles: a tile's aggregate is published as soon as it is shaded, but its look-back
+    // is resolved - and its survivors are written - only after the NEXT tile has been shaded.  By then the workgroups that own
+    // the preceding tiles have long published theirs, so the scan no longer stalls the workgroup for the skew between its
+    // neighbours (measured: 9-10 us of waiting per tile against 5-8 us of shading when resolved immediately).
+#ifdef RT355_SHADE_TIMING
+    long long tShade = 0, tDrain = 0, tBegin = wall_clock64(); int nT = 0;
+#endif
+    bool pend = false, pExt = false, pSh = false;
+    uint32_t pTile = 0;
+    unsigned long long pEm = 0ull, pSm = 0ull;
+    int par = 0;
+    for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x, par ^= 1) {
         const int i = (int)tile * kBlock + threadIdx.x;
         if (threadIdx.x == 0) q.tile[nxt][1 + tile] = 0ull;     // arm shade(bounce+1)'s scan (its queue is never longer)
+#ifdef RT355_SHADE_TIMING
+        const long long c0 = wall_clock64();
+#endif
 
         bool extValid = false, shValid = false;
+        ExtRay ext; ext.valid = false;
+        uint2 extMeta = make_uint2(0u, 0u);
         if (i < n) {
-            ExtRay ext; ext.valid = false;
-            ShadowOut sh; sh.valid = false; sh.a = &sShA[threadIdx.x]; sh.b = &sShB[threadIdx.x]; sh.c = &sShC[threadIdx.x];
+            ShadowOut sh; sh.valid = false; sh.a = &sShA[par][threadIdx.x]; sh.b = &sShB[par][threadIdx.x]; sh.c = &sShC[par][threadIdx.x];
             const float4 hit = q.hit[i];
             const uint2 meta = q.meta[cur][i];
             SRay ray;
@@ -1101,54 +1159,43 @@ __global__ __launch_bounds__(kBlock, 5) void k_shade(DevScene sc, DevQueues q, D
                     q.accum[ray.pixel] = add4(q.accum[ray.pixel], color);
                 if (ext.valid && ext.bounces <= RT_MAX_BOUNCES) {   // wavefront.cl:129
                     extValid = true;
-                    sExtO[threadIdx.x] = ext.O; sExtD[threadIdx.x] = ext.D; sExtI[threadIdx.x] = ext.inten;
-                    sExtM[threadIdx.x] = make_uint2((uint32_t)ray.pixel, (uint32_t)ext.bounces | (ext.inside ? kMetaInside : 0u) | (ext.lastSpec ? kMetaLastSpec : 0u));
+                    extMeta = make_uint2((uint32_t)ray.pixel, (uint32_t)ext.bounces | (ext.inside ? kMetaInside : 0u) | (ext.lastSpec ? kMetaLastSpec : 0u));
                 }
                 shValid = sh.valid;
             }
         }
-        // wave votes + ordered scan across tiles (replaces atomic_inc on numOutRays / shadowRays, wavefront.cl:131,136)
+        // wave votes; publish the tile's counts at once (replaces atomic_inc on numOutRays / shadowRays, wavefront.cl:131,136)
         const unsigned long long em = __ballot(extValid), sm = __ballot(shValid);
-        if (lane == 0) { sWaveE[wave] = (uint32_t)__popcll(em); sWaveS[wave] = (uint32_t)__popcll(sm); }
+        if (lane == 0) { sWaveE[par][wave] = (uint32_t)__popcll(em); sWaveS[par][wave] = (uint32_t)__popcll(sm); }
         __syncthreads();
         if (wave == 0) {
             uint32_t aggE = 0, aggS = 0;
 #pragma unroll
-            for (int w = 0; w < kBlock / 64; w++) { aggE += sWaveE[w]; aggS += sWaveS[w]; }
-            // Two-level ordered scan.  Level 1: tiles publish their counts; a tile sums the counts of the earlier tiles of
-            // its own super-tile (64 tiles, one 64-lane read).  Level 2: the last tile of a super-tile publishes the
-            // super-tile total and resolves its inclusive prefix by decoupled look-back over the (<= a few hundred)
-            // super-tile words; every tile then adds the inclusive prefix of the previous super-tile.  All waits are on
-            // smaller tile ids (see the kernel comment).  Flag and payload share one 8-byte word (agent-scope atomics).
-            const uint32_t sup = tile >> 6, inSup = tile & 63u;
+            for (int w = 0; w < kBlock / 64; w++) { aggE += sWaveE[par][w]; aggS += sWaveS[par][w]; }
+            const uint32_t sup = tile >> 6;
+            unsigned long long acc = 0ull;
             if (lane == 0) {
                 __hip_atomic_store(&state[1 + tile], tile_pack(kTileAgg, aggE, aggS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (inSup == 0) super[nxt][sup] = 0ull;           // arm shade(bounce+1)'s level 2
+                if ((tile & 63u) == 0u) { super[nxt][sup] = 0ull; q.supAcc[nxt][sup] = 0ull; }   // arm shade(bounce+1)'s level 2
+                // one relaxed add carries this tile's counts AND its arrival, so the 64th arrival holds the super-tile's totals
+                // in the value the add returns: nothing else has to be visible to it, no fence is needed
+                acc = __hip_atomic_fetch_add(&q.supAcc[cur][sup], (1ull << 40) | ((unsigned long long)aggE << 20) | (unsigned long long)aggS,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            uint32_t inE = 0, inS = 0;                            // counts of tiles [64*sup, tile)
-            {
-                unsigned long long v = 0ull;
-                if ((uint32_t)lane < inSup) {
-                    const uint32_t t = (sup << 6) + (uint32_t)lane;
-                    v = wait_word(&state[1 + t], 0ull, q.fault);
-                }
-                inE = tile_ext(v); inS = tile_sh(v);
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) { inE += __shfl_xor(inE, off, 64); inS += __shfl_xor(inS, off, 64); }
-            }
-            uint32_t preE = 0, preS = 0;                          // inclusive prefix of super-tiles [0, sup)
-            if (inSup == 63u) {
-                // this tile closes its super-tile: publish the total, then look back over the super-tile words
-                const uint32_t totE = inE + aggE, totS = inS + aggS;
+            acc = __shfl(acc, 0, 64);
+            if ((acc >> 40) == 63ull) {
+                // Level 2: the LAST of its 64 tiles to arrive closes a super-tile, at once and whichever tile it is: publish the
+                // total, resolve the inclusive prefix by decoupled look-back over the earlier super-tile words (<= a few hundred;
+                // waits only on smaller ids) and publish it.
+                const uint32_t totE = (uint32_t)((acc >> 20) & 0xfffffull) + aggE, totS = (uint32_t)(acc & 0xfffffull) + aggS;
+                uint32_t preE = 0, preS = 0;
                 if (sup > 0) {
                     if (lane == 0) __hip_atomic_store(&super[cur][sup], tile_pack(kTileAgg, totE, totS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     int top = (int)sup - 1;
                     for (;;) {
-                        const int t = top - lane;
+                        const int tt = top - lane;
                         unsigned long long v = kTilePrefix;
-                        if (t >= 0) {
-                            v = wait_word(&super[cur][t], 0ull, q.fault);
-                        }
+                        if (tt >= 0) v = wait_word(&super[cur][tt], 0ull, q.fault);
                         const unsigned long long isPre = __ballot((v >> 62) == 2ull);
                         const int stop = isPre ? __ffsll((long long)isPre) - 1 : 64;
                         uint32_t e = lane <= stop ? tile_ext(v) : 0u, s2 = lane <= stop ? tile_sh(v) : 0u;
@@ -1160,33 +1207,27 @@ __global__ __launch_bounds__(kBlock, 5) void k_shade(DevScene sc, DevQueues q, D
                     }
                 }
                 if (lane == 0) __hip_atomic_store(&super[cur][sup], tile_pack(kTilePrefix, preE + totE, preS + totS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (sup > 0) {
-                unsigned long long v = 0ull;
-                if (lane == 0) {
-                    v = wait_word(&super[cur][sup - 1], 2ull, q.fault);
-                }
-                preE = tile_ext(v); preS = tile_sh(v);            // lane 0 holds it; only lane 0 uses it below
-            }
-            if (lane == 0) {
-                sBaseE = preE + inE; sBaseS = preS + inS;
-                if (tile == numTiles - 1) { q.nRays[bounce + 1] = (int)(preE + inE + aggE); q.nShadow[bounce + 1] = shadowBase + (int)(preS + inS + aggS); }
             }
         }
-        __syncthreads();
-        uint32_t baseE = sBaseE, baseS = sBaseS + (uint32_t)shadowBase;
-        for (int w = 0; w < wave; w++) { baseE += sWaveE[w]; baseS += sWaveS[w]; }
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (extValid) {
-            const uint32_t dst = baseE + (uint32_t)__popcll(em & below);
-            q.O[nxt][dst] = sExtO[threadIdx.x]; q.D[nxt][dst] = sExtD[threadIdx.x]; q.inten[nxt][dst] = sExtI[threadIdx.x];
-            q.meta[nxt][dst] = sExtM[threadIdx.x];
-        }
-        if (shValid) {
-            const uint32_t dst = baseS + (uint32_t)__popcll(sm & below);
-            q.sA[dst] = sShA[threadIdx.x]; q.sB[dst] = sShB[threadIdx.x]; q.sC[dst] = sShC[threadIdx.x];
-        }
-        __syncthreads();   // LDS words are reused by the next tile
+#ifdef RT355_SHADE_TIMING
+        const long long c1 = wall_clock64();
+#endif
+        if (pend) drain(pTile, par ^ 1, pEm, pSm, pExt, pSh);
+#ifdef RT355_SHADE_TIMING
+        tShade += c1 - c0; tDrain += wall_clock64() - c1; nT++;
+#endif
+        // park this tile's extension ray (its shadow record went to sSh*[par] while shading)
+        if (extValid) { sExtO[threadIdx.x] = ext.O; sExtD[threadIdx.x] = ext.D; sExtI[threadIdx.x] = ext.inten; sExtM[threadIdx.x] = extMeta; }
+        pend = true; pTile = tile; pEm = em; pSm = sm; pExt = extValid; pSh = shValid;
     }
+    if (pend) {
+        __syncthreads();   // the parked extension rays of the last tile
+        drain(pTile, par ^ 1, pEm, pSm, pExt, pSh);
+    }
+#ifdef RT355_SHADE_TIMING
+    if (threadIdx.x == 0 && (blockIdx.x & 127) == 5 && bounce <= 1)
+        printf("shade b%d block %d tiles %d: shade %lld drain %lld total %lld (x10 ns)\n", bounce, blockIdx.x, nT, tShade, tDrain, wall_clock64() - tBegin);
+#endif
 }
 
 // ------------------------------------------------------------------ k_connect: any-hit over shadow rays [nShadow[b0], nShadow[b1+1])
