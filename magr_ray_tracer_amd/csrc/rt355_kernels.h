@@ -1117,6 +1117,16 @@ __global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, D
     uint32_t pTile = 0;
     unsigned long long pEm = 0ull, pSm = 0ull;
     int par = 0;
+    // the queue entries of the NEXT tile are fetched before the previous tile is drained, so their latency hides behind the drain
+    struct TileIn { float4 hit, O, D, inten; uint2 meta; uint32_t seed; };
+    auto fetch = [&](uint32_t t, TileIn& in) {
+        const int j = (int)t * kBlock + threadIdx.x;
+        if (t < numTiles && j < n) {
+            in.hit = q.hit[j]; in.meta = q.meta[cur][j]; in.O = q.O[cur][j]; in.D = q.D[cur][j]; in.inten = q.inten[cur][j]; in.seed = q.seeds[j];
+        }
+    };
+    TileIn in;
+    fetch(blockIdx.x, in);
     for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x, par ^= 1) {
         const int i = (int)tile * kBlock + threadIdx.x;
         if (threadIdx.x == 0) q.tile[nxt][1 + tile] = 0ull;     // arm shade(bounce+1)'s scan (its queue is never longer)
@@ -1129,10 +1139,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, D
         uint2 extMeta = make_uint2(0u, 0u);
         if (i < n) {
             ShadowOut sh; sh.valid = false; sh.a = &sShA[par][threadIdx.x]; sh.b = &sShB[par][threadIdx.x]; sh.c = &sShC[par][threadIdx.x];
-            const float4 hit = q.hit[i];
-            const uint2 meta = q.meta[cur][i];
+            const float4 hit = in.hit;
+            const uint2 meta = in.meta;
             SRay ray;
-            ray.O = q.O[cur][i]; ray.D = q.D[cur][i]; ray.inten = q.inten[cur][i];
+            ray.O = in.O; ray.D = in.D; ray.inten = in.inten;
             ray.t = hit.x; ray.prim = __float_as_int(hit.y); ray.u = hit.z; ray.v = hit.w;
             ray.pixel = (int)meta.x; ray.bounces = (int)(meta.y & kMetaBounceMask);
             ray.inside = (meta.y & kMetaInside) != 0; ray.lastSpec = (meta.y & kMetaLastSpec) != 0;
@@ -1150,7 +1160,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, D
                 ray.N = (tag >> 28) == RT_PRIM_SPHERE ? prim_normal(sc.prims + ray.prim, ray.I)
                                                       : mk4(rec.x, rec.y, rec.z, (tag & 0x08000000u) ? -0.0f : 0.0f);   // flipped normals carry w = -0
                 if (dot4(ray.N, neg4(ray.D)) < 0) ray.N = muls(ray.N, -1.0f);
-                uint32_t seed = q.seeds[i];
+                uint32_t seed = in.seed;
                 float4 color = shade_hit<NEE>(sc, var, ray, seed, ext, sh);
                 q.seeds[i] = seed;
                 color = firefly(var.fireflies, color);
@@ -1212,7 +1222,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, D
 #ifdef RT355_SHADE_TIMING
         const long long c1 = wall_clock64();
 #endif
+        TileIn inNext;
+        fetch(tile + gridDim.x, inNext);
         if (pend) drain(pTile, par ^ 1, pEm, pSm, pExt, pSh);
+        in = inNext;
 #ifdef RT355_SHADE_TIMING
         tShade += c1 - c0; tDrain += wall_clock64() - c1; nT++;
 #endif
