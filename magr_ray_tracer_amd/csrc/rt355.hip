@@ -152,16 +152,17 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     ctx->gridMax = (ctx->nPix * std::max(1, c.max_bounces) + kBlock - 1) / kBlock; // connect may cover max_bounces*nPix shadow rays
     ctx->gridMax = std::max(ctx->gridMax, 4096);                                    // and the persistent grid (<= 256 CUs x 8 blocks)
     ctx->var = DevVariant{ c.shading, c.sampling, c.accel, c.russian_roulette ? 1 : 0, c.filter_fireflies ? 1 : 0, c.max_bounces };
-    {   // k_shade's grid must be co-resident.  The occupancy query knows the VGPR, LDS and wave-slot limits but not the SGPR file:
-        // 256-thread workgroups are admitted up to min(query, 8, 800 / (ceil16(sgprs) + 16)) per CU (MI355X_MICROARCH.md, residency),
-        // which is 6 for any kernel (<= 112 SGPRs) and 7 up to 96 SGPRs.  k_shade is held to 4 by its registers and 39 KB of LDS.
+    {   // k_shade: as many workgroups as the CUs hold at once.  Its ordered scan does not depend on that (tiles go by ticket to
+        // running workgroups), so the size only matters for speed.  The occupancy query knows the VGPR, LDS and wave-slot limits
+        // but not the SGPR file: 256-thread workgroups are admitted up to min(query, 8, 800 / (ceil16(sgprs) + 16)) per CU
+        // (MI355X_MICROARCH.md, residency) = 6 for any kernel (<= 112 SGPRs), 7 up to 96 SGPRs.  k_shade: 4 (registers, 39 KB LDS).
         hipDeviceProp_t prop; int perCU = 0;
         HIPCHK(hipGetDeviceProperties(&prop, c.device));
         if (c.shading == RT_SHADING_NEE) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<true>, kBlock, 0));
         else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<false>, kBlock, 0));
         perCU = std::min(perCU, kAdmitAnySgpr);
         ctx->shadeGrid = prop.multiProcessorCount * std::max(1, perCU);
-        if (const char* g = getenv("RT355_SHADE_PER_CU")) { int v = atoi(g); if (v > 0 && v <= std::max(1, perCU)) ctx->shadeGrid = prop.multiProcessorCount * v; }
+        if (const char* g = getenv("RT355_SHADE_PER_CU")) { int v = atoi(g); if (v > 0 && v <= 16) ctx->shadeGrid = prop.multiProcessorCount * v; }   // tuning / over-subscription tests
     }
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(RT_E_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -174,7 +175,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     for (int k = 0; k < 2; k++) { QA(O[k], n); QA(D[k], n); QA(inten[k], n); QA(meta[k], n); QA(tile[k], nTiles + 2); QA(super[k], nTiles / 64 + 2); QA(supAcc[k], nTiles / 64 + 2); }
     QA(hit, n);
     QA(sA, nS); QA(sB, nS); QA(sC, nS);
-    QA(nRays, RT_MAX_BOUNCES + 2); QA(nShadow, RT_MAX_BOUNCES + 2); QA(cursor, 2 * (RT_MAX_BOUNCES + 2)); QA(fault, 1);
+    QA(nRays, RT_MAX_BOUNCES + 2); QA(nShadow, RT_MAX_BOUNCES + 2); QA(cursor, kCursorWords); QA(shadeTicket, (size_t)(RT_MAX_BOUNCES + 1) * kTicketClasses * kTicketStride); QA(fault, 1);
     QA(seeds, n); QA(accum, (size_t)c.width * c.height);
     if (rc == RT_OK) rc = dalloc(bag, &ctx->dSteps, n);
     q.steps = nullptr;
@@ -186,7 +187,8 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     (void)hipMemsetAsync(q.accum, 0, sizeof(float4) * (size_t)c.width * c.height, ctx->stream);
     (void)hipMemsetAsync(q.nRays, 0, sizeof(int32_t) * (RT_MAX_BOUNCES + 2), ctx->stream);
     (void)hipMemsetAsync(q.nShadow, 0, sizeof(int32_t) * (RT_MAX_BOUNCES + 2), ctx->stream);
-    (void)hipMemsetAsync(q.cursor, 0, sizeof(int32_t) * 2 * (RT_MAX_BOUNCES + 2), ctx->stream);
+    (void)hipMemsetAsync(q.cursor, 0, sizeof(int32_t) * kCursorWords, ctx->stream);
+    (void)hipMemsetAsync(q.shadeTicket, 0, sizeof(int32_t) * (size_t)(RT_MAX_BOUNCES + 1) * kTicketClasses * kTicketStride, ctx->stream);
     (void)hipMemsetAsync(q.fault, 0, sizeof(int32_t), ctx->stream);
     (void)hipMemsetAsync(q.ctrExtend, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
     (void)hipMemsetAsync(q.ctrConnect, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
@@ -516,7 +518,7 @@ static inline dim3 grid_for(int n) { return dim3((unsigned)std::max(1, (n + kBlo
 extern "C" int rt_stage_begin_frame(RtCtx* ctx)
 {
     if (!ctx) return fail(RT_E_INVALID, "rt_stage_begin_frame: null context");
-    hipLaunchKernelGGL(k_begin_frame, dim3(1), dim3(64), 0, ctx->stream, ctx->q);
+    hipLaunchKernelGGL(k_begin_frame, dim3(1), dim3(256), 0, ctx->stream, ctx->q);
     HIPCHK(hipGetLastError());
     memset(ctx->cursorUsed, 0, sizeof ctx->cursorUsed);
     memset(ctx->shadeRun, 0, sizeof ctx->shadeRun);
@@ -575,6 +577,7 @@ extern "C" int rt_stage_shade(RtCtx* ctx, int32_t bounce)
         HIPCHK(hipMemsetAsync(ctx->q.tile[bounce & 1], 0, sizeof(unsigned long long) * (nTiles + 2), ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->q.super[bounce & 1], 0, sizeof(unsigned long long) * (nTiles / 64 + 2), ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->q.supAcc[bounce & 1], 0, sizeof(unsigned long long) * (nTiles / 64 + 2), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->q.shadeTicket + (size_t)bounce * kTicketClasses * kTicketStride, 0, sizeof(int32_t) * (size_t)kTicketClasses * kTicketStride, ctx->stream));
     }
     ev_begin(ctx, ST_SHADE);
     const dim3 sg((unsigned)std::max(1, std::min(ctx->shadeGrid, (ctx->nPix + kBlock - 1) / kBlock)));

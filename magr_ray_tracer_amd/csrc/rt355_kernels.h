@@ -69,6 +69,7 @@ struct DevQueues {
     int32_t* nShadow;  // [RT_MAX_BOUNCES+2]  shadow rays of bounce b occupy [nShadow[b], nShadow[b+1])
     int32_t* fault;    // [1] set to 1 by a kernel whose bounded wait expired (host turns it into RT_E_DEVICE)
     int32_t* cursor;   // [2*(RT_MAX_BOUNCES+2)] work-queue heads of the persistent kernels (extend: [b], connect: [9+b])
+    int32_t* shadeTicket; // [(RT_MAX_BOUNCES+1) * kTicketClasses * kTicketStride] k_shade's tile tickets, one counter per bounce and class
     uint32_t* seeds;   // one RNG stream per band slot
     float4* accum;     // full frame, indexed by global pixel index
     int32_t* steps;    // per-ray steps of the last extend (debug / heat map), may be null
@@ -76,6 +77,10 @@ struct DevQueues {
     unsigned long long* ctrConnect; // [gridMax][5]
     int32_t nPix, firstPixel, width, height;
 };
+// k_shade hands its tiles out through kTicketClasses counters (class c serves tiles c, c + K, c + 2K, ...), 4 KB apart so that
+// they sit in different memory channels: one counter would take all ~8,100 tickets of a 1080p launch at the chip's ~88 same-address
+// atomics per microsecond
+static constexpr int kTicketClasses = 32, kTicketStride = 1024, kCursorWords = 2 * (RT_MAX_BOUNCES + 2);
 struct DevVariant { int32_t shading, sampling, accel, rr, fireflies, maxBounces; };
 
 // meta.y bit layout
@@ -472,7 +477,8 @@ __global__ void k_reset(float4* accum, int32_t first, int32_t n)
 __global__ void k_begin_frame(DevQueues q) // renderer.cpp:66-69
 {
     if (threadIdx.x == 0) { q.nRays[0] = q.nPix; q.nShadow[0] = 0; }
-    if (threadIdx.x < 2 * (RT_MAX_BOUNCES + 2)) q.cursor[threadIdx.x] = 0;
+    if (threadIdx.x < kCursorWords) q.cursor[threadIdx.x] = 0;
+    for (int k = threadIdx.x; k < (RT_MAX_BOUNCES + 1) * kTicketClasses; k += blockDim.x) q.shadeTicket[(size_t)k * kTicketStride] = 0;
 }
 
 // ------------------------------------------------------------------ k_generate
@@ -1022,12 +1028,8 @@ RT_FORCEINLINE unsigned long long tile_pack(unsigned long long flag, uint32_t e,
 RT_FORCEINLINE uint32_t tile_ext(unsigned long long v) { return (uint32_t)((v >> 31) & 0x7fffffffull); }
 RT_FORCEINLINE uint32_t tile_sh(unsigned long long v) { return (uint32_t)(v & 0x7fffffffull); }
 
-// Persistent workgroups, static round-robin tiles: workgroup g shades tiles g, g+G, g+2G, ... in increasing
-// order (tile = 256 consecutive queue slots).  Publishing a tile's counts waits for nothing; closing a super-tile and
-// resolving a tile's position only wait for words of smaller tile / super-tile ids, and those belong to workgroups of the
-// same launch that process their own tiles in increasing order, so by induction over the id every wait ends as long as the
-// G workgroups are co-resident - the host launches what the hardware admits per CU (4: registers and LDS; see rt_create)
-// and uses no ticket atomics (8,100 tickets on one word cost ~90 us per launch on this chip, more than the shading itself).
+// Persistent workgroups take tiles (256 consecutive queue slots) by ticket (see the kernel).  Publishing a tile's counts waits
+// for nothing; closing a super-tile and resolving a tile's position only wait for words of smaller tile / super-tile ids.
 // Bounded wait on a status word: every spin in this library has an upper bound (~seconds), after which the kernel raises
 // q.fault and carries on with a zero payload instead of hanging the GPU; the host reports RT_E_DEVICE.
 static constexpr uint32_t kSpinLimit = 1u << 22;   // x ~1-2 us per poll: several seconds
@@ -1125,11 +1127,28 @@ __global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, D
             in.hit = q.hit[j]; in.meta = q.meta[cur][j]; in.O = q.O[cur][j]; in.D = q.D[cur][j]; in.inten = q.inten[cur][j]; in.seed = q.seeds[j];
         }
     };
+    // Tiles are handed out by ticket to workgroups that are RUNNING.  Class c = blockIdx.x mod K owns tiles c, c + K, c + 2K, ... and
+    // hands them out in increasing order, one ticket = one tile (K = kTicketClasses counters instead of one: see there).  What a tile
+    // waits for are words of smaller tile / super-tile ids; the smallest unpublished tile is either held by a running workgroup, which
+    // publishes before it waits for anything newer, or is the next ticket of its class, which a running workgroup of that class draws
+    // as soon as its own (smaller, hence published) tile is done.  So the scan needs one running workgroup per class - K workgroups
+    // with consecutive ids - not a co-resident grid, and it also gets through when the GPU is shared with other work.
+    __shared__ uint32_t sTicket;
+    const uint32_t cls = blockIdx.x % (uint32_t)kTicketClasses;
+    int32_t* ticket = q.shadeTicket + ((size_t)bounce * kTicketClasses + cls) * kTicketStride;
+    uint32_t tkNext = 0;                                   // thread 0: ticket of the next tile (drawn while this one is shaded)
+    if (threadIdx.x == 0) sTicket = (uint32_t)atomicAdd(ticket, 1);
+    __syncthreads();
+    uint32_t tile = sTicket * (uint32_t)kTicketClasses + cls;
+    __syncthreads();                                       // sTicket is rewritten inside the loop
     TileIn in;
-    fetch(blockIdx.x, in);
-    for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x, par ^= 1) {
+    fetch(tile, in);
+    for (; tile < numTiles; par ^= 1) {
         const int i = (int)tile * kBlock + threadIdx.x;
-        if (threadIdx.x == 0) q.tile[nxt][1 + tile] = 0ull;     // arm shade(bounce+1)'s scan (its queue is never longer)
+        if (threadIdx.x == 0) {
+            q.tile[nxt][1 + tile] = 0ull;     // arm shade(bounce+1)'s scan (its queue is never longer)
+            tkNext = (uint32_t)atomicAdd(ticket, 1);
+        }
 #ifdef RT355_SHADE_TIMING
         const long long c0 = wall_clock64();
 #endif
@@ -1177,6 +1196,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, D
         // wave votes; publish the tile's counts at once (replaces atomic_inc on numOutRays / shadowRays, wavefront.cl:131,136)
         const unsigned long long em = __ballot(extValid), sm = __ballot(shValid);
         if (lane == 0) { sWaveE[par][wave] = (uint32_t)__popcll(em); sWaveS[par][wave] = (uint32_t)__popcll(sm); }
+        if (threadIdx.x == 0) sTicket = tkNext;
         __syncthreads();
         if (wave == 0) {
             uint32_t aggE = 0, aggS = 0;
@@ -1222,9 +1242,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, D
 #ifdef RT355_SHADE_TIMING
         const long long c1 = wall_clock64();
 #endif
+        const uint32_t nextTile = sTicket * (uint32_t)kTicketClasses + cls;
         TileIn inNext;
-        fetch(tile + gridDim.x, inNext);
+        fetch(nextTile, inNext);
         if (pend) drain(pTile, par ^ 1, pEm, pSm, pExt, pSh);
+        else __syncthreads();   // everybody has read sTicket before thread 0 takes the next one
         in = inNext;
 #ifdef RT355_SHADE_TIMING
         tShade += c1 - c0; tDrain += wall_clock64() - c1; nT++;
@@ -1232,6 +1254,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, D
         // park this tile's extension ray (its shadow record went to sSh*[par] while shading)
         if (extValid) { sExtO[threadIdx.x] = ext.O; sExtD[threadIdx.x] = ext.D; sExtI[threadIdx.x] = ext.inten; sExtM[threadIdx.x] = extMeta; }
         pend = true; pTile = tile; pEm = em; pSm = sm; pExt = extValid; pSh = shValid;
+        tile = nextTile;
     }
     if (pend) {
         __syncthreads();   // the parked extension rays of the last tile

@@ -578,3 +578,39 @@ def test_persistent_wavefronts_vs_oracle(accel, monkeypatch):
     _ctr_equal(out[0][2], e, c)
     assert out[0][2]["extend_rays"] > 3 * 65536          # the long-queue branch really ran
     assert bits_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][3], out[1][3])
+
+
+def _render_crc(args):
+    """Child process: render `frames` frames of the 1280x720 sponza-class scene and return a checksum of accumulator and RNG state."""
+    frames, env = args
+    import os
+    os.environ.update(env)
+    import numpy as np
+    from magr_ray_tracer_amd import scenes
+    from magr_ray_tracer_amd.renderer import Device
+    Wd, Hd = 1280, 720
+    s, view = scenes.sponza_class(0.5)
+    d = Device(Wd, Hd, **DEFAULT)
+    d.upload(s.arrays())
+    d.seed_default()
+    d.render(scenes.camera_for(view, Wd, Hd), frames)
+    d.synchronize()
+    out = (int(d.read_accum().view(np.uint32).astype(np.uint64).sum()), int(d.get_seeds().astype(np.uint64).sum()))
+    d.close()
+    return out
+
+
+def test_shared_gpu_and_oversubscribed_grid():
+    """k_shade's ordered scan must not depend on its whole grid being resident: two processes rendering on the same GPU at the same
+    time, and a grid of four times what the CUs hold (RT355_SHADE_PER_CU=16), finish without a device fault and reproduce the
+    single-process image and RNG state bit for bit."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(1) as pool:
+        solo = pool.map(_render_crc, [(24, {})])[0]
+    with ctx.Pool(1) as pool:
+        over = pool.map(_render_crc, [(24, {"RT355_SHADE_PER_CU": "16"})])[0]
+    with ctx.Pool(2) as pool:
+        both = pool.map(_render_crc, [(24, {}), (24, {})], chunksize=1)
+    assert over == solo
+    assert both[0] == solo and both[1] == solo
