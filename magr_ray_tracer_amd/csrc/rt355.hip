@@ -56,7 +56,7 @@ struct RtCtx {
     PersistTune tune{ 64, 20, 6, 8 };
     float4* dPostF = nullptr; uchar4* dPostB = nullptr;   // post-processing outputs (lazy)
     int32_t* dSteps = nullptr;   // per-ray `steps` buffer, only bound while rt_debug_enable_steps is on
-    int shadeGrid = 1024;   // co-resident workgroups of k_shade (see the kernel's comment); set in rt_create
+    int shadeGrid = 1024;   // workgroups of k_shade (what the CUs hold at once; the kernel does not depend on it); set in rt_create
 };
 enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_COMPACT, ST_CONNECT, ST_ACCUM };
 
