@@ -53,7 +53,7 @@ struct RtCtx {
     bool shadeRun[RT_MAX_BOUNCES + 1] = {};           // shade(b) launched since the last k_begin_frame
     bool generated = false;                           // generate launched since the last k_begin_frame
     int stackEntries = RT_BVH2_STACK, persistGrid = 0, persistGridConnect = 0;
-    PersistTune tune{ 64, 20, 6, 8 };
+    PersistTune tune{ 64, 20, 6, 8 }, tuneConnect{ 128, 32, 6, 8 };   // measured optima (profiles/r01_persist_tuning.log, tools/tune_connect.sh)
     float4* dPostF = nullptr; uchar4* dPostB = nullptr;   // post-processing outputs (lazy)
     int32_t* dSteps = nullptr;   // per-ray `steps` buffer, only bound while rt_debug_enable_steps is on
     int shadeGrid = 1024;   // workgroups of k_shade (what the CUs hold at once; the kernel does not depend on it); set in rt_create
@@ -442,8 +442,12 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner,leafK[,blocksPerCU]" (tuning aid)
             int a = 0, b = 0, c = 0, l = 0, d = 0;
             int k = sscanf(t, "%d,%d,%d,%d,%d", &a, &b, &c, &l, &d);
-            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = PersistTune{ a, b, c, l };
+            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = ctx->tuneConnect = PersistTune{ a, b, c, l };
             if (k == 5 && d > 0) ctx->persistGrid = ctx->persistGridConnect = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount);
+        }
+        if (const char* t = getenv("RT355_TUNE_CONNECT")) { // same fields, connect launches only
+            int a = 0, b = 0, c = 0, l = 0;
+            if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l };
         }
     }
     ctx->sc = sc;
@@ -602,9 +606,9 @@ extern "C" int rt_stage_connect(RtCtx* ctx, int32_t b0, int32_t b1)
     }
     ev_begin(ctx, ST_CONNECT);
     if (ctx->persist4)
-        hipLaunchKernelGGL((k_trace_persist4<true>), dim3(ctx->persistGridConnect), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1, 0, ctx->tune);
+        hipLaunchKernelGGL((k_trace_persist4<true>), dim3(ctx->persistGridConnect), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1, 0, ctx->tuneConnect);
     else if (ctx->persist)
-        hipLaunchKernelGGL((k_trace_persist<true>), dim3(ctx->persistGridConnect), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1, 0, ctx->tune);
+        hipLaunchKernelGGL((k_trace_persist<true>), dim3(ctx->persistGridConnect), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1, 0, ctx->tuneConnect);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4 && ctx->layout == 1)
         hipLaunchKernelGGL((k_connect<RT_ACCEL_BVH4, 1>), grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4)
