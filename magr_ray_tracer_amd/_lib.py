@@ -63,7 +63,7 @@ DEVICE_SYMBOLS = [
     "rt_stage_begin_frame", "rt_stage_generate", "rt_stage_extend", "rt_stage_shade", "rt_stage_connect",
     "rt_debug_get_rays", "rt_debug_set_rays", "rt_debug_get_shadow", "rt_debug_enable_steps", "rt_debug_get_steps"]
 HOST_SYMBOLS = [
-    "rth_last_error", "rth_scene_create", "rth_scene_destroy", "rth_add_material", "rth_add_texture", "rth_add_sphere",
+    "rth_last_error", "rth_scene_create", "rth_scene_destroy", "rth_add_material", "rth_add_texture", "rth_load_texture", "rth_add_sphere",
     "rth_add_plane", "rth_add_triangle", "rth_add_quad", "rth_add_triangles", "rth_build_blas", "rth_build_bvh4",
     "rth_build_tlas", "rth_set_instance_transform", "rth_primitives", "rth_materials", "rth_textures", "rth_lights",
     "rth_bvh2_nodes", "rth_bvh4_nodes", "rth_prim_idx", "rth_tlas_nodes", "rth_blas_nodes", "rth_bvh_stats", "rth_camera",
@@ -144,6 +144,7 @@ def host_lib():
         lib.rth_scene_destroy.argtypes = [vp]
         lib.rth_add_material.argtypes = [vp, cp, vp]
         lib.rth_add_texture.argtypes = [vp, cp, vp, i32, i32]
+        lib.rth_load_texture.argtypes = [vp, cp, cp]
         lib.rth_add_sphere.argtypes = [vp, fp, C.c_float, cp]
         lib.rth_add_plane.argtypes = [vp, fp, C.c_float, cp]
         lib.rth_add_triangle.argtypes = [vp, fp, fp, fp, fp, fp, fp, cp, i32]

@@ -52,7 +52,7 @@ def build_host(force=False):
                    os.path.join(ROOT, "include", "rt355_host.h"), os.path.join(ROOT, "include", "rt355_types.h")]
     out = os.path.join(PKG, "librt355_host.so")
     if force or _stale(out, deps):
-        _run(["g++"] + HOST_FLAGS + srcs + ["-o", out, "-L" + PKG, "-lrt355", "-Wl,-rpath,$ORIGIN"])
+        _run(["g++"] + HOST_FLAGS + srcs + ["-o", out, "-L" + PKG, "-lrt355", "-lz", "-Wl,-rpath,$ORIGIN"])
     return out
 
 

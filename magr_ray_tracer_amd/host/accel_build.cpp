@@ -14,6 +14,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <stdexcept>
 #include <cstring>
 #include <future>
 #include <mutex>
@@ -586,6 +587,7 @@ void TLAS::Build()
 {
     int slot[256], live = (int)bvh2_.blasNodes.size();
     if (live > 256) live = 256; // reference limit: nodeIdx[256], 16-bit child ids
+    if (live == 0) throw std::runtime_error("TLAS::Build: the scene has no BLAS (BuildBLAS comes first)");   // the reference reads slot[0] uninitialised here
     nodesUsed_ = 1;
     for (int i = 0; i < live; i++) {
         const RtBVHNode2& root = bvh2_.bvhNodes[bvh2_.blasNodes[i].bvhIdx];

@@ -37,6 +37,11 @@ int rth_add_texture(RthScene* s, const char* name, const RtFloat4* texels, int w
     if (!s || !name || !texels || w <= 0 || h <= 0) { g_herr = "rth_add_texture: bad argument"; return -1; }
     try { return s->scene.AddTexture(texels, w, h, name); } catch (const std::exception& e) { g_herr = e.what(); return -1; }
 }
+int rth_load_texture(RthScene* s, const char* filename, const char* name)
+{
+    if (!s || !filename || !name) { g_herr = "rth_load_texture: null argument"; return -1; }
+    try { return s->scene.LoadTexture(filename, name); } catch (const std::exception& e) { g_herr = e.what(); return -1; }
+}
 int rth_add_sphere(RthScene* s, const float pos[3], float radius, const char* material) { GUARD(s->scene.AddSphere(f3(pos), radius, material)) }
 int rth_add_plane(RthScene* s, const float N[3], float d, const char* material) { GUARD(s->scene.AddPlane(f3(N), d, material)) }
 int rth_add_triangle(RthScene* s, const float v0[3], const float v1[3], const float v2[3], const float uv0[2], const float uv1[2],

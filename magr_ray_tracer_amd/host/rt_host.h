@@ -118,7 +118,7 @@ private:
     uint32_t nodesUsed_ = 0;
 };
 
-// reference: src/scene.h:5-34 (LoadModel / LoadTexture file IO is a "next" row)
+// reference: src/scene.h:5-34 (LoadModel / LoadTexture file IO: scene_io.cpp, image_io.cpp)
 class Scene {
 public:
     Scene();
@@ -131,6 +131,8 @@ public:
     void AddTriangle(float3 v0, float3 v1, float3 v2, float2 uv0, float2 uv1, float2 uv2, const std::string& material,
                      bool flipNormal = false);
     int  AddTexture(const RtFloat4* texels, int width, int height, const std::string& name); // LoadTexture minus the file read
+    // reference: Scene::LoadTexture (scene.cpp:244-256); PNG, TGA and Radiance HDR files (image_io.cpp); returns the material index
+    int  LoadTexture(const std::string& filename, const std::string& name);
     int  MaterialIndex(const std::string& name);
     bool HasMaterial(const std::string& name) const { return matMap_.count(name) != 0; }
     // reference: Scene::LoadModel (scene.cpp:178-243), OBJ + MTL diffuse-texture names; returns the triangles added
@@ -150,6 +152,8 @@ private:
 
 // reference: SaveImageF (template/template.cpp:1629-1644) behind Renderer::SaveFrame (renderer.cpp:303-308)
 void SavePNG(const std::string& file, int w, int h, const RtFloat4* data);
+// LoadImageF (template/template.cpp:1613-1627): w*h RGB float triples, top row first (image_io.cpp)
+std::vector<float> LoadImageF(const std::string& file, int& w, int& h);
 
 // reference: src/camera.h:7-122 (aspect = width/height is a run-time value here)
 class CameraManager {

@@ -1,8 +1,8 @@
 // scene_build.cpp — Scene primitive/material factory and CameraManager maths.
 // Mirrors reference src/scene.cpp:84-176 (AddMaterial, AddSphere, AddPlane, AddQuad,
 // AddTriangle: geometric normal, centroid, Heron area, light list) and
-// src/camera.h:24-121 (Fov, UpdateCamVec).  File IO (LoadModel/LoadTexture) is a
-// "next" row; AddTexture takes texels that are already in memory.
+// src/camera.h:24-121 (Fov, UpdateCamVec).  File IO (LoadModel, LoadTexture) lives in
+// scene_io.cpp / image_io.cpp; AddTexture takes texels that are already in memory.
 #include <cmath>
 #include <cstring>
 #include "rt_host.h"

@@ -85,6 +85,11 @@ class Scene:
         assert t.shape[2] == 4
         return self._chk(self._lib.rth_add_texture(self._h, name.encode(), _lib.ptr(t), w, h))
 
+    # reference: Scene::LoadTexture (scene.cpp:244-256); PNG, TGA and Radiance HDR files
+    def LoadTexture(self, filename, name):
+        """Read an image file into the texture atlas and add a material `name` that points at it; returns the material index."""
+        return self._chk(self._lib.rth_load_texture(self._h, str(filename).encode(), name.encode()))
+
     def AddSphere(self, pos, radius, material):
         self._chk(self._lib.rth_add_sphere(self._h, _lib.fvec(pos), float(radius), material.encode()))
         self.num_prims += 1
@@ -138,6 +143,13 @@ class Scene:
         self._lib.rth_bvh_stats(self._h, _lib.ptr(u), _lib.ptr(f))
         return {"depth": int(u[0]), "nodes": int(u[1]), "spatial_splits": int(u[2]), "prims_clipped": int(u[3]),
                 "prims": int(u[4]), "sah_cost": float(f[0]), "build_ms": float(f[1])}
+
+    def texture_array(self):
+        """Scene::textures as an (n, 4) float32 view (no acceleration structure needed)."""
+        return _view(self._lib.rth_textures, self._h, np.dtype((np.float32, 4)))
+
+    def material_array(self):
+        return _view(self._lib.rth_materials, self._h, _lib.Material)
 
     def arrays(self, bvh4=True):
         L = self._lib
