@@ -22,6 +22,9 @@ CASES = {
     "mixed_nee": (lambda: scenes.mixed_scene(textured=True), dict(forward=(0.32, 0.75, 0.92)), 4, dict()),
     "mixed_kajiya_hemi": (lambda: scenes.mixed_scene(textured=True), dict(forward=(0.32, 0.75, 0.92)), 4,
                           dict(shading=0, sampling=0, russian_roulette=False, filter_fireflies=False)),
+    "mixed_nee_hemi_norr": (lambda: scenes.mixed_scene(textured=True), dict(forward=(0.32, 0.75, 0.92)), 4,
+                            dict(sampling=0, russian_roulette=False)),
+    "mixed_kajiya_cos_rr": (lambda: scenes.mixed_scene(textured=True), dict(forward=(0.32, 0.75, 0.92)), 4, dict(shading=0)),
     "cube_nee_bvh4": (scenes.cube_scene, dict(forward=(0.5, 0.9, 0.82)), 4, dict(accel=1)),
     "twoblas_nee": (lambda: scenes.two_blas_scene(alpha=0.0, n=10), dict(forward=(0.02, 0.8, 0.97)), 4, dict()),
 }

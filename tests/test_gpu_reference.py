@@ -64,7 +64,14 @@ def test_focus_matches_reference_kernel():
     ref.close()
 
 
-@pytest.mark.parametrize("vi", [dict(), dict(shading=0, sampling=0, russian_roulette=False, filter_fireflies=False)])
+@pytest.mark.parametrize("vi", [
+    dict(),                                                                         # NEE, cosine, RR, firefly filter (BASELINE config 3)
+    dict(shading=0, sampling=0, russian_roulette=False, filter_fireflies=False),    # Kajiya, hemisphere (config 2 family)
+    dict(sampling=0, russian_roulette=False),                                       # NEE, hemisphere, fixed path length
+    dict(shading=0, sampling=1),                                                    # Kajiya, cosine, RR, firefly filter
+    dict(filter_fireflies=False),                                                   # NEE without the firefly clamp
+    dict(accel=1),                                                                  # NEE over the BVH4
+])
 def test_shade_connect_s0_oracle_vs_reference_kernels(vi):
     v = dict(DEFAULT, **vi)
     rows = 8
