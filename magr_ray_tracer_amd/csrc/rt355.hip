@@ -364,16 +364,32 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         bool fits = true;
         for (int32_t i = 0; i < nNodes && fits; i++) if (n2[i].count > 127) fits = false;
         if (fits) {
-            auto entry = [&](uint32_t i) { return n2[i].count > 0 ? (0x80000000u | (n2[i].count << 24) | n2[i].first) : i; };
+            // Interior nodes are renumbered breadth-first, BLAS by BLAS, and stored densely: the reference array interleaves leaves
+            // and interior nodes (children are allocated in pairs), so a table indexed by the reference's node id would be half
+            // holes; breadth-first puts the top levels of the (first) tree, which every ray visits, into the first records.
+            std::vector<uint32_t> newId((size_t)nNodes, 0xffffffffu), order;
+            order.reserve((size_t)nNodes / 2 + 1);
+            for (int32_t b = 0; b < nBlas; b++) {
+                const uint32_t root = blas[b].bvhIdx;
+                if (n2[root].count > 0 || newId[root] != 0xffffffffu) continue;
+                size_t head = order.size();
+                newId[root] = (uint32_t)order.size(); order.push_back(root);
+                for (; head < order.size(); head++) {
+                    const uint32_t i = order[head];
+                    for (uint32_t c = n2[i].first; c <= n2[i].first + 1; c++)
+                        if (n2[c].count == 0 && newId[c] == 0xffffffffu) { newId[c] = (uint32_t)order.size(); order.push_back(c); }
+                }
+            }
+            auto entry = [&](uint32_t i) { return n2[i].count > 0 ? (0x80000000u | (n2[i].count << 24) | n2[i].first) : newId[i]; };
             auto f2u = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
-            std::vector<float4> pairs((size_t)nNodes * 4, make_float4(0, 0, 0, 0));
-            for (int32_t i = 0; i < nNodes; i++) {
-                if (n2[i].count > 0) continue;
+            std::vector<float4> pairs(std::max<size_t>(order.size(), 1) * 4, make_float4(0, 0, 0, 0));
+            for (size_t k = 0; k < order.size(); k++) {
+                const uint32_t i = order[k];
                 const RtBVHNode2& a = n2[n2[i].first]; const RtBVHNode2& b = n2[n2[i].first + 1];
-                pairs[(size_t)i * 4 + 0] = make_float4(a.aabbMin.x, a.aabbMin.y, a.aabbMin.z, a.aabbMax.x);
-                pairs[(size_t)i * 4 + 1] = make_float4(a.aabbMax.y, a.aabbMax.z, b.aabbMin.x, b.aabbMin.y);
-                pairs[(size_t)i * 4 + 2] = make_float4(b.aabbMin.z, b.aabbMax.x, b.aabbMax.y, b.aabbMax.z);
-                pairs[(size_t)i * 4 + 3] = make_float4(f2u(entry(n2[i].first)), f2u(entry(n2[i].first + 1)), 0, 0);
+                pairs[k * 4 + 0] = make_float4(a.aabbMin.x, a.aabbMin.y, a.aabbMin.z, a.aabbMax.x);
+                pairs[k * 4 + 1] = make_float4(a.aabbMax.y, a.aabbMax.z, b.aabbMin.x, b.aabbMin.y);
+                pairs[k * 4 + 2] = make_float4(b.aabbMin.z, b.aabbMax.x, b.aabbMax.y, b.aabbMax.z);
+                pairs[k * 4 + 3] = make_float4(f2u(entry(n2[i].first)), f2u(entry(n2[i].first + 1)), 0, 0);
             }
             std::vector<float4> recs((size_t)nIdx * 3);
             for (int32_t s = 0; s < nIdx; s++) {
