@@ -614,3 +614,17 @@ def test_shared_gpu_and_oversubscribed_grid():
         both = pool.map(_render_crc, [(24, {}), (24, {})], chunksize=1)
     assert over == solo
     assert both[0] == solo and both[1] == solo
+
+
+@pytest.mark.parametrize("Wd,Hd", [(250, 141), (256, 64), (512, 96), (513, 33)])
+def test_odd_sizes_and_full_super_tiles(Wd, Hd):
+    """Queue lengths around the scan's structure: 250x141 = 138 tiles (two closed super-tiles and a partial one, width not a multiple
+    of the 8x8 primary-ray tiling), 256x64 = exactly one closed super-tile, 512x96 = exactly three, 513x33 ragged in every respect."""
+    sa, cam, o, d = _pair(lambda: scenes.sponza_class(0.2), Wd, Hd, DEFAULT)
+    acc, seeds, e, c = o.render(cam, 2)
+    d.seed_default()
+    d.render(cam, 2)
+    assert_bits(d.read_accum(), acc, f"{Wd}x{Hd}")
+    assert np.array_equal(d.get_seeds(), seeds)
+    _ctr_equal(d.counters(), e, c)
+    d.close()
