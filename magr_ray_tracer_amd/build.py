@@ -56,6 +56,16 @@ def build_host(force=False):
     return out
 
 
+def build_examples(force=False):
+    """examples/headless_tick: the reference's main loop, headless, on the host mirror + C-ABI (C++ drop-in check)."""
+    src = os.path.join(ROOT, "examples", "headless_tick.cpp")
+    out = os.path.join(ROOT, "examples", "headless_tick")
+    deps = [src, os.path.join(PKG, "host", "rt_host.h"), os.path.join(PKG, "librt355_host.so"), os.path.join(PKG, "librt355.so")]
+    if force or _stale(out, deps):
+        _run(["g++", "-O2", "-std=c++17", "-Wall", src, "-o", out, "-L" + PKG, "-lrt355_host", "-lrt355", "-Wl,-rpath,$ORIGIN/../magr_ray_tracer_amd"])
+    return out
+
+
 def build_oracle(force=False):
     odir = os.path.join(ROOT, "oracle")
     src = os.path.join(odir, "oracle.c")
@@ -75,6 +85,7 @@ def build_ref(force=False):
 def build_all(force=False):
     build_device(force)
     build_host(force)
+    build_examples(force)
     build_oracle(force)
     build_ref(force)
 

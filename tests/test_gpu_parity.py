@@ -628,3 +628,47 @@ def test_odd_sizes_and_full_super_tiles(Wd, Hd):
     assert np.array_equal(d.get_seeds(), seeds)
     _ctr_equal(d.counters(), e, c)
     d.close()
+
+
+def test_cpp_headless_tick_example(tmp_path):
+    """The C++ drop-in path: examples/headless_tick drives Scene / BVH2 / Renderer::Init / Tick / SaveFrame of the host mirror from C++
+    (the reference's main loop without its window), with a PNG texture read by Scene::LoadTexture.  Two runs are deterministic,
+    BVH2 and BVH4 agree on the image up to the QBVH's tie order, and the PNG carries the frame."""
+    import os
+    import subprocess
+    import zlib
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "headless_tick")
+    assert os.path.exists(exe), "examples/headless_tick is built by magr_ray_tracer_amd.build.build_examples()"
+    tex = tmp_path / "checker.png"
+    yy, xx = np.mgrid[0:64, 0:64]
+    img = np.zeros((64, 64, 4), np.float32)
+    img[..., 0] = ((xx // 8 + yy // 8) % 2) * 0.8 + 0.1
+    img[..., 1] = 0.5
+    img[..., 2] = ((xx // 8 + yy // 8 + 1) % 2) * 0.8 + 0.1
+    from magr_ray_tracer_amd.scene import save_png
+    save_png(tex, img)
+
+    def run(out, *extra):
+        r = subprocess.run([exe, "--size", "320", "180", "--spp", "8", "--tex", str(tex), "--out", str(out), *extra],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        line = [l for l in r.stdout.splitlines() if l.startswith("headless_tick:")][0]
+        return float(line.split("energy ")[1].split(",")[0]), out.read_bytes()
+
+    e1, p1 = run(tmp_path / "a.png")
+    e2, p2 = run(tmp_path / "b.png")
+    assert e1 == e2 and p1 == p2 and e1 > 0
+    e4, _ = run(tmp_path / "c.png", "--bvh4")
+    assert abs(e4 - e1) <= 1e-3 * e1
+    # the PNG decodes to a 320x180 RGB frame that is not black
+    assert p1[:8] == b"\x89PNG\r\n\x1a\n" and int.from_bytes(p1[16:20], "big") == 320 and int.from_bytes(p1[20:24], "big") == 180
+    idat = b"".join(p1[i + 8:i + 8 + int.from_bytes(p1[i:i + 4], "big")] for i in _png_chunks(p1) if p1[i + 4:i + 8] == b"IDAT")
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(180, 1 + 320 * 3)
+    assert raw[:, 1:].mean() > 10
+
+
+def _png_chunks(b):
+    i = 8
+    while i + 12 <= len(b):
+        yield i
+        i += 12 + int.from_bytes(b[i:i + 4], "big")
