@@ -2,6 +2,7 @@
 // sequence.  This is the replacement for the reference's OpenCL Kernel/Buffer dispatch in
 // Renderer (src/renderer.cpp:64-94,142-263,289-301).  No CPU fallback exists here.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -120,6 +121,21 @@ static void ev_end(RtCtx* c, int stage)
     (void)hipEventRecord(c->evPool[c->evUsed % kEvRing].b, c->stream);
     c->evUsed++;
 }
+// A single launch is timed by the events the dispatch itself carries (hipExtLaunchKernelGGL: start/stop are the kernel's own begin/end
+// timestamps, no marker packets on the stream - bracketing a launch with hipEventRecord costs ~2 % of a frame at 24 launches).
+static RtCtx::Ev& ev_slot(RtCtx* c, int stage)
+{
+    ev_init(c);
+    RtCtx::Ev& e = c->evPool[c->evUsed % kEvRing];
+    if (e.stage >= 0) ev_account(c, e);   // ring wrapped: harvest the oldest pair first
+    e.stage = stage;
+    c->evUsed++;
+    return e;
+}
+#define LAUNCH(ctx, stage, kernel, grid, shmem, ...) do { \
+        if (ev_on(ctx, stage)) { RtCtx::Ev& e_ = ev_slot(ctx, stage); hipExtLaunchKernelGGL(kernel, grid, dim3(kBlock), (uint32_t)(shmem), (ctx)->stream, e_.a, e_.b, 0, __VA_ARGS__); } \
+        else hipLaunchKernelGGL(kernel, grid, dim3(kBlock), shmem, (ctx)->stream, __VA_ARGS__); \
+    } while (0)
 static void ev_collect(RtCtx* c) // call after a stream sync
 {
     for (auto& e : c->evPool) if (e.stage >= 0) ev_account(c, e);
@@ -548,9 +564,7 @@ extern "C" int rt_stage_begin_frame(RtCtx* ctx)
 extern "C" int rt_stage_generate(RtCtx* ctx, const RtCamera* cam, const RtSettings* s)
 {
     if (!ctx || !cam) return fail(RT_E_INVALID, "rt_stage_generate: null argument");
-    ev_begin(ctx, ST_GENERATE);
-    hipLaunchKernelGGL(k_generate, grid_for(ctx->nPix), dim3(kBlock), 0, ctx->stream, ctx->q, *cam, s ? s->antiAliasing : 1);
-    ev_end(ctx, ST_GENERATE);
+    LAUNCH(ctx, ST_GENERATE, k_generate, grid_for(ctx->nPix), 0, ctx->q, *cam, s ? s->antiAliasing : 1);
     HIPCHK(hipGetLastError());
     ctx->primaryRays += (uint64_t)ctx->nPix;
     ctx->generated = true;
@@ -564,25 +578,23 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
         if (ctx->cursorUsed[bounce]) HIPCHK(hipMemsetAsync(ctx->q.cursor + bounce, 0, sizeof(int32_t), ctx->stream));
         ctx->cursorUsed[bounce] = true;
     }
-    ev_begin(ctx, ST_EXTEND);
     // bounce 0: primary rays are coherent and finish together, refilling buys nothing -> one ray per lane
     if (ctx->persist4)
-        hipLaunchKernelGGL((k_trace_persist4<false>), bounce > 0 ? dim3(ctx->persistGrid) : grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+        LAUNCH(ctx, ST_EXTEND, (k_trace_persist4<false>), bounce > 0 ? dim3(ctx->persistGrid) : grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
     else if (ctx->persist && (bounce > 0 || ctx->cfg.extend_variant == 3))
-        hipLaunchKernelGGL((k_trace_persist<false>), dim3(ctx->persistGrid), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+        LAUNCH(ctx, ST_EXTEND, (k_trace_persist<false>), dim3(ctx->persistGrid), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
     else if (ctx->persist && ctx->cfg.extend_variant != 5)
         // bounce 0 through the same kernel with one workgroup per 256 rays: its "queue not longer than the grid" branch is the plain
         // one-ray-per-lane loop without the TLAS code of k_extend (60 instead of 86 VGPRs: 8 instead of 5 waves per SIMD)
-        hipLaunchKernelGGL((k_trace_persist<false>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+        LAUNCH(ctx, ST_EXTEND, (k_trace_persist<false>), grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4 && ctx->layout == 1)
-        hipLaunchKernelGGL((k_extend<RT_ACCEL_BVH4, 1>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
+        LAUNCH(ctx, ST_EXTEND, (k_extend<RT_ACCEL_BVH4, 1>), grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, renderBVH);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4)
-        hipLaunchKernelGGL((k_extend<RT_ACCEL_BVH4, 0>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
+        LAUNCH(ctx, ST_EXTEND, (k_extend<RT_ACCEL_BVH4, 0>), grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, renderBVH);
     else if (ctx->layout == 1)
-        hipLaunchKernelGGL((k_extend<RT_ACCEL_BVH2, 1>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
+        LAUNCH(ctx, ST_EXTEND, (k_extend<RT_ACCEL_BVH2, 1>), grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, renderBVH);
     else
-        hipLaunchKernelGGL((k_extend<RT_ACCEL_BVH2, 0>), grid_for(ctx->nPix), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, bounce, renderBVH);
-    ev_end(ctx, ST_EXTEND);
+        LAUNCH(ctx, ST_EXTEND, (k_extend<RT_ACCEL_BVH2, 0>), grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, renderBVH);
     HIPCHK(hipGetLastError());
     return RT_OK;
 }
@@ -599,13 +611,11 @@ extern "C" int rt_stage_shade(RtCtx* ctx, int32_t bounce)
         HIPCHK(hipMemsetAsync(ctx->q.supAcc[bounce & 1], 0, sizeof(unsigned long long) * (nTiles / 64 + 2), ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->q.shadeTicket + (size_t)bounce * kTicketClasses * kTicketStride, 0, sizeof(int32_t) * (size_t)kTicketClasses * kTicketStride, ctx->stream));
     }
-    ev_begin(ctx, ST_SHADE);
     const dim3 sg((unsigned)std::max(1, std::min(ctx->shadeGrid, (ctx->nPix + kBlock - 1) / kBlock)));
     if (ctx->cfg.shading == RT_SHADING_NEE)
-        hipLaunchKernelGGL(k_shade<true>, sg, dim3(kBlock), 0, ctx->stream, ctx->sc, ctx->q, ctx->var, bounce);
+        LAUNCH(ctx, ST_SHADE, k_shade<true>, sg, 0, ctx->sc, ctx->q, ctx->var, bounce);
     else
-        hipLaunchKernelGGL(k_shade<false>, sg, dim3(kBlock), 0, ctx->stream, ctx->sc, ctx->q, ctx->var, bounce);
-    ev_end(ctx, ST_SHADE);
+        LAUNCH(ctx, ST_SHADE, k_shade<false>, sg, 0, ctx->sc, ctx->q, ctx->var, bounce);
     ctx->shadeRun[bounce] = true;
     HIPCHK(hipGetLastError());
     return RT_OK;
@@ -620,20 +630,18 @@ extern "C" int rt_stage_connect(RtCtx* ctx, int32_t b0, int32_t b1)
         if (ctx->cursorUsed[ci]) HIPCHK(hipMemsetAsync(ctx->q.cursor + ci, 0, sizeof(int32_t), ctx->stream));
         ctx->cursorUsed[ci] = true;
     }
-    ev_begin(ctx, ST_CONNECT);
     if (ctx->persist4)
-        hipLaunchKernelGGL((k_trace_persist4<true>), dim3(ctx->persistGridConnect), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1, 0, ctx->tuneConnect);
+        LAUNCH(ctx, ST_CONNECT, (k_trace_persist4<true>), dim3(ctx->persistGridConnect), stack_bytes(ctx), ctx->sc, ctx->q, b0, b1, 0, ctx->tuneConnect);
     else if (ctx->persist)
-        hipLaunchKernelGGL((k_trace_persist<true>), dim3(ctx->persistGridConnect), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1, 0, ctx->tuneConnect);
+        LAUNCH(ctx, ST_CONNECT, (k_trace_persist<true>), dim3(ctx->persistGridConnect), stack_bytes(ctx), ctx->sc, ctx->q, b0, b1, 0, ctx->tuneConnect);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4 && ctx->layout == 1)
-        hipLaunchKernelGGL((k_connect<RT_ACCEL_BVH4, 1>), grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
+        LAUNCH(ctx, ST_CONNECT, (k_connect<RT_ACCEL_BVH4, 1>), grid_for(cap), stack_bytes(ctx), ctx->sc, ctx->q, b0, b1);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4)
-        hipLaunchKernelGGL((k_connect<RT_ACCEL_BVH4, 0>), grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
+        LAUNCH(ctx, ST_CONNECT, (k_connect<RT_ACCEL_BVH4, 0>), grid_for(cap), stack_bytes(ctx), ctx->sc, ctx->q, b0, b1);
     else if (ctx->layout == 1)
-        hipLaunchKernelGGL((k_connect<RT_ACCEL_BVH2, 1>), grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
+        LAUNCH(ctx, ST_CONNECT, (k_connect<RT_ACCEL_BVH2, 1>), grid_for(cap), stack_bytes(ctx), ctx->sc, ctx->q, b0, b1);
     else
-        hipLaunchKernelGGL((k_connect<RT_ACCEL_BVH2, 0>), grid_for(cap), dim3(kBlock), stack_bytes(ctx), ctx->stream, ctx->sc, ctx->q, b0, b1);
-    ev_end(ctx, ST_CONNECT);
+        LAUNCH(ctx, ST_CONNECT, (k_connect<RT_ACCEL_BVH2, 0>), grid_for(cap), stack_bytes(ctx), ctx->sc, ctx->q, b0, b1);
     ev_begin(ctx, ST_ACCUM);
     for (int b = b0; b <= b1; b++)
         hipLaunchKernelGGL(k_accumulate, grid_for(ctx->nPix), dim3(kBlock), 0, ctx->stream, ctx->q, b);
