@@ -430,19 +430,40 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         for (int32_t i = 0; i < nNodes && fits; i++) for (int k = 0; k < 4; k++) if (n4[i].first[k] != RT_INVALID && n4[i].count[k] > 127) fits = false;
         if (fits) {
             auto f2u = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
-            std::vector<float4> quads((size_t)nNodes * 8, make_float4(0, 0, 0, 0));
-            for (int32_t i = 0; i < nNodes; i++) {
+            // The collapse (bvh.cpp:695-803) leaves the absorbed BVH2 nodes in the array: only the nodes still reachable from a BLAS
+            // root are kept, renumbered breadth-first and stored densely (on the bench scene 1 node in 4 is alive).
+            std::vector<uint32_t> newId((size_t)nNodes, 0xffffffffu), order;
+            for (int32_t b = 0; b < nBlas; b++) {
+                const uint32_t root = blas[b].bvhIdx;
+                if (newId[root] != 0xffffffffu) continue;
+                size_t head = order.size();
+                newId[root] = (uint32_t)order.size(); order.push_back(root);
+                for (; head < order.size(); head++) {
+                    const uint32_t i = order[head];
+                    for (int k = 0; k < 4; k++) {
+                        if (n4[i].first[k] == RT_INVALID || n4[i].count[k] > 0) continue;
+                        const uint32_t c = (uint32_t)n4[i].first[k];
+                        if (newId[c] == 0xffffffffu) { newId[c] = (uint32_t)order.size(); order.push_back(c); }
+                    }
+                }
+            }
+            std::vector<float4> quads(std::max<size_t>(order.size(), 1) * 8, make_float4(0, 0, 0, 0));
+            for (size_t q = 0; q < order.size(); q++) {
+                const uint32_t i = order[q];
                 float b[24]; uint32_t e[4];
                 for (int k = 0; k < 4; k++) {
                     const RtFloat4& mn = n4[i].aabbMin[k]; const RtFloat4& mx = n4[i].aabbMax[k];
                     b[k * 6 + 0] = mn.x; b[k * 6 + 1] = mn.y; b[k * 6 + 2] = mn.z; b[k * 6 + 3] = mx.x; b[k * 6 + 4] = mx.y; b[k * 6 + 5] = mx.z;
                     if (n4[i].first[k] == RT_INVALID) e[k] = 0xffffffffu;
                     else if (n4[i].count[k] > 0) e[k] = 0x80000000u | ((uint32_t)n4[i].count[k] << 24) | (uint32_t)n4[i].first[k];
-                    else e[k] = (uint32_t)n4[i].first[k];
+                    else e[k] = newId[(uint32_t)n4[i].first[k]];
                 }
-                for (int v = 0; v < 6; v++) quads[(size_t)i * 8 + v] = make_float4(b[v * 4], b[v * 4 + 1], b[v * 4 + 2], b[v * 4 + 3]);
-                quads[(size_t)i * 8 + 6] = make_float4(f2u(e[0]), f2u(e[1]), f2u(e[2]), f2u(e[3]));
+                for (int v = 0; v < 6; v++) quads[q * 8 + v] = make_float4(b[v * 4], b[v * 4 + 1], b[v * 4 + 2], b[v * 4 + 3]);
+                quads[q * 8 + 6] = make_float4(f2u(e[0]), f2u(e[1]), f2u(e[2]), f2u(e[3]));
             }
+            std::vector<uint32_t> roots((size_t)nBlas);
+            for (int32_t b = 0; b < nBlas; b++) roots[b] = newId[blas[b].bvhIdx];
+            if (rc == RT_OK) rc = upload(ctx, &sc.rootEntry, roots.data(), roots.size());
             std::vector<float4> recs((size_t)nIdx * 3);
             for (int32_t s = 0; s < nIdx; s++) {
                 const RtPrimitive& p = prims[primIdx[s]];

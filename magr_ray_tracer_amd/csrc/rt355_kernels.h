@@ -405,7 +405,7 @@ RT_FORCEINLINE int traverse_instance(const DevScene& sc, TRay& r, const RtBVHIns
     r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
     wc.inst++;
     int steps;
-    if (ACCEL == RT_ACCEL_BVH4) steps = LAYOUT == 1 ? traverse_bvh4_packed<OCC>(sc, r, inst->bvhIdx, stk, wc) : traverse_bvh4<OCC>(sc, r, inst->bvhIdx, stk, wc);
+    if (ACCEL == RT_ACCEL_BVH4) steps = LAYOUT == 1 ? traverse_bvh4_packed<OCC>(sc, r, sc.rootEntry[instIdx], stk, wc) : traverse_bvh4<OCC>(sc, r, inst->bvhIdx, stk, wc);
     else if (LAYOUT == 1) steps = traverse_bvh2_packed<OCC>(sc, r, sc.rootEntry[instIdx], stk, wc);
     else steps = traverse_bvh2<OCC>(sc, r, inst->bvhIdx, stk, wc);
     r.ox = bx; r.oy = by; r.oz = bz; r.dx = bdx; r.dy = bdy; r.dz = bdz; r.rx = brx; r.ry = bry; r.rz = brz;
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist4(DevScene sc, DevQueue
     const int n = OCC ? q.nShadow[b1 + 1] - qFirst : q.nRays[b0];
     int32_t* cursor = q.cursor + (OCC ? (RT_MAX_BOUNCES + 2) + b0 : b0);
     const RtBVHInstance* inst = sc.blas + sc.tlas[0].BLASidx;
-    const uint32_t rootNode = inst->bvhIdx;
+    const uint32_t rootNode = sc.rootEntry[sc.tlas[0].BLASidx];   // id of the root in the dense quad table
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = inst->invT[k];
