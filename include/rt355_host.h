@@ -26,7 +26,7 @@ void      rth_scene_destroy(RthScene* s);
 int rth_add_material(RthScene* s, const char* name, const RtMaterial* init);
 /* Scene::LoadTexture minus the file read (scene.cpp:244-256): appends texels, adds a material. */
 int rth_add_texture(RthScene* s, const char* name, const RtFloat4* texels, int width, int height);
-/* Scene::LoadTexture (scene.cpp:244-256) for PNG, TGA and Radiance HDR files, texel rule of stbi_loadf; returns the material index or -1. */
+/* Scene::LoadTexture (scene.cpp:244-256) for PNG, JPEG, TGA and Radiance HDR files, texel rule of stbi_loadf; returns the material index or -1. */
 int rth_load_texture(RthScene* s, const char* filename, const char* name);
 int rth_add_sphere(RthScene* s, const float pos[3], float radius, const char* material);       /* scene.cpp:125-138 */
 int rth_add_plane(RthScene* s, const float N[3], float d, const char* material);               /* scene.cpp:140-150 */

@@ -1,6 +1,6 @@
 // image_io.cpp — texture files for Scene::LoadTexture (reference: src/scene.cpp:244-256 -> LoadImageF,
 // template/template.cpp:1613-1627 -> stbi_loadf of the vendored stb_image).  Readers written from the format
-// specifications (PNG 1.2 / RFC 1950-1951 through zlib, Radiance RGBE, Truevision TGA 2.0); what is taken over from the
+// specifications (PNG 1.2 / RFC 1950-1951 through zlib, Radiance RGBE, Truevision TGA 2.0; JPEG: jpeg_io.cpp); what is taken over from the
 // reference's pipeline is the pixel rule it applies afterwards:
 //   * 8-bit sources become float by stb's ldr->hdr rule, (float)(pow(v / 255.0f, 2.2f) * 1.0f) evaluated in double
 //     (lib/stb_image.h:1553,1849); 16-bit PNG samples are first reduced to their high byte;
@@ -8,8 +8,8 @@
 //   * LoadImageF keeps channels 0..2; grey images are expanded to r = g = b here (the reference indexes past the pixel
 //     for 1- and 2-channel files, template.cpp:1621-1623, which is undefined behaviour, not a convention to mirror);
 //   * texels are appended to Scene::textures as float4 with w = 0 (float4(float3), template.cpp:810-814).
-// Not read: JPEG (no decoder here; stb's IDCT/upsampling rounding would have to be matched sample for sample and no
-// reference test pins it), interlaced PNG.  Parity of this file with stb_image is unpinned beyond the rules above.
+// JPEG files go through jpeg_io.cpp (decoders differ by +-1..2 levels in IDCT / chroma interpolation / colour rounding: unpinned).
+// Not read: interlaced PNG.  Parity of this file with stb_image is unpinned beyond the rules above.
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -200,6 +200,16 @@ std::vector<float> LoadImageF(const std::string& file, int& w, int& h)
         w = im.w; h = im.h;
         return out;
     }
+    if (b.size() >= 2 && b[0] == 0xff && b[1] == 0xd8) {
+        Image8 im;
+        DecodeJpeg(b, file, im.w, im.h, im.rgb);
+        float lut[256];
+        for (int v = 0; v < 256; v++) lut[v] = (float)(pow(v / 255.0f, 2.2f) * 1.0f);
+        std::vector<float> out(im.rgb.size());
+        for (size_t i = 0; i < out.size(); i++) out[i] = lut[im.rgb[i]];
+        w = im.w; h = im.h;
+        return out;
+    }
     if (b.size() >= 2 && b[0] == '#' && b[1] == '?') { ImageF im = decodeHdr(b, file); w = im.w; h = im.h; return im.rgb; }
     const size_t dot = file.find_last_of('.');
     std::string ext = dot == std::string::npos ? "" : file.substr(dot + 1);
@@ -213,7 +223,7 @@ std::vector<float> LoadImageF(const std::string& file, int& w, int& h)
         w = im.w; h = im.h;
         return out;
     }
-    throw std::runtime_error("LoadTexture: " + file + ": unsupported image format (PNG, TGA and Radiance HDR are read; JPEG is not)");
+    throw std::runtime_error("LoadTexture: " + file + ": unsupported image format (PNG, JPEG, TGA and Radiance HDR are read)");
 }
 
 int Scene::LoadTexture(const std::string& filename, const std::string& name) // scene.cpp:244-256

@@ -131,7 +131,7 @@ public:
     void AddTriangle(float3 v0, float3 v1, float3 v2, float2 uv0, float2 uv1, float2 uv2, const std::string& material,
                      bool flipNormal = false);
     int  AddTexture(const RtFloat4* texels, int width, int height, const std::string& name); // LoadTexture minus the file read
-    // reference: Scene::LoadTexture (scene.cpp:244-256); PNG, TGA and Radiance HDR files (image_io.cpp); returns the material index
+    // reference: Scene::LoadTexture (scene.cpp:244-256); PNG, JPEG, TGA and Radiance HDR files (image_io.cpp, jpeg_io.cpp); returns the material index
     int  LoadTexture(const std::string& filename, const std::string& name);
     int  MaterialIndex(const std::string& name);
     bool HasMaterial(const std::string& name) const { return matMap_.count(name) != 0; }
@@ -154,6 +154,8 @@ private:
 void SavePNG(const std::string& file, int w, int h, const RtFloat4* data);
 // LoadImageF (template/template.cpp:1613-1627): w*h RGB float triples, top row first (image_io.cpp)
 std::vector<float> LoadImageF(const std::string& file, int& w, int& h);
+// ITU-T T.81 baseline / progressive Huffman JPEG -> 8-bit RGB, top row first (jpeg_io.cpp)
+void DecodeJpeg(const std::vector<uint8_t>& bytes, const std::string& file, int& w, int& h, std::vector<uint8_t>& rgb);
 
 // reference: src/camera.h:7-122 (aspect = width/height is a run-time value here)
 class CameraManager {

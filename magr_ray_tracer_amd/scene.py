@@ -85,7 +85,7 @@ class Scene:
         assert t.shape[2] == 4
         return self._chk(self._lib.rth_add_texture(self._h, name.encode(), _lib.ptr(t), w, h))
 
-    # reference: Scene::LoadTexture (scene.cpp:244-256); PNG, TGA and Radiance HDR files
+    # reference: Scene::LoadTexture (scene.cpp:244-256); PNG, JPEG, TGA and Radiance HDR files
     def LoadTexture(self, filename, name):
         """Read an image file into the texture atlas and add a material `name` that points at it; returns the material index."""
         return self._chk(self._lib.rth_load_texture(self._h, str(filename).encode(), name.encode()))

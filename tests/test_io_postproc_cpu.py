@@ -332,6 +332,58 @@ def test_load_texture_hdr_and_tga(tmp_path):
     assert np.array_equal(got.view(np.uint32), _stb_float(bgra[:, :, 2::-1]).view(np.uint32))
 
 
+def _loaded_bytes(path):
+    """LoadTexture(path) mapped back to 8-bit levels through the inverse of stbi_loadf's rule (exact: the rule is a 256-entry table)."""
+    s = Scene()
+    mi = s.LoadTexture(path, "t")
+    m = s.material_array()[mi]
+    w, h = int(m["texW"]), int(m["texH"])
+    tex = _texels(s)[:, :3]
+    lut = _stb_float(np.arange(256))
+    idx = np.clip(np.searchsorted(lut, tex.ravel()), 0, 255)
+    assert np.array_equal(lut[idx], tex.ravel())
+    return idx.reshape(h, w, 3).astype(np.int32)
+
+
+def test_load_texture_jpeg_against_libjpeg(tmp_path):
+    """Baseline / progressive, 4:4:4 / 4:2:2 / 4:2:0 / grey, optimised Huffman tables, restart markers, odd sizes: within the +-3
+    levels by which conforming decoders differ (IDCT, chroma interpolation and colour rounding are not fixed by T.81) of
+    Pillow's libjpeg-turbo.  JPEG texel parity with the reference's stb_image is unpinned (jpeg_io.cpp)."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:157, 0:203]
+    base = np.stack([(np.sin(xx / 9.0) + 1) * 100 + rng.integers(0, 20, xx.shape), (np.cos(yy / 7.0) + 1) * 90 + 30,
+                     ((xx + yy) % 64) * 3 + rng.integers(0, 30, xx.shape)], -1).clip(0, 255).astype(np.uint8)
+    colour, grey = Image.fromarray(base), Image.fromarray(base[..., 0])
+    cases = [("base420", colour, dict(quality=85, subsampling=2)), ("base444", colour, dict(quality=90, subsampling=0)),
+             ("base422", colour, dict(quality=75, subsampling=1)), ("prog420", colour, dict(quality=85, subsampling=2, progressive=True)),
+             ("prog444", colour, dict(quality=92, subsampling=0, progressive=True)), ("opt", colour, dict(quality=60, subsampling=2, optimize=True)),
+             ("rst", colour, dict(quality=85, subsampling=2, restart_marker_blocks=3)),
+             ("grey", grey, dict(quality=80)), ("greyprog", grey, dict(quality=80, progressive=True)),
+             ("tiny", colour.crop((0, 0, 5, 3)), dict(quality=90, subsampling=2))]
+    for name, im, kw in cases:
+        f = tmp_path / (name + ".jpg")
+        im.save(f, "JPEG", **kw)
+        ref = np.asarray(Image.open(f).convert("RGB")).astype(np.int32)
+        got = _loaded_bytes(f)
+        assert got.shape == ref.shape, name
+        d = np.abs(got - ref)
+        assert d.max() <= 4 and d.mean() < 0.25, (name, int(d.max()), float(d.mean()))
+
+
+def test_load_texture_png_against_pillow(tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(9)
+    rgb = rng.integers(0, 256, (37, 53, 3)).astype(np.uint8)
+    for name, im in (("rgb", Image.fromarray(rgb)), ("rgba", Image.fromarray(np.dstack([rgb, rgb[..., :1]]))),
+                     ("pal", Image.fromarray(rgb).quantize(17)), ("grey", Image.fromarray(rgb[..., 0])),
+                     ("bilevel", Image.fromarray(rgb[..., 0] > 127))):
+        f = tmp_path / (name + ".png")
+        im.save(f, "PNG", optimize=(name != "rgb"))
+        ref = np.asarray(Image.open(f).convert("RGB")).astype(np.int32)
+        assert np.array_equal(_loaded_bytes(f), ref), name
+
+
 def test_load_texture_errors(tmp_path):
     s = Scene()
     with pytest.raises(Exception, match="no BLAS"):     # an empty scene is an error, not a crash
