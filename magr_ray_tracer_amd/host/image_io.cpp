@@ -61,7 +61,7 @@ Image8 decodePng(const std::vector<uint8_t>& b, const std::string& file)
         else if (!memcmp(type, "IEND", 4)) seenEnd = true;
         pos += 12 + (size_t)len;
     }
-    if (!seenIhdr || w <= 0 || h <= 0 || (int64_t)w * h > (1 << 28)) throw bad("bad PNG header");
+    if (!seenIhdr || w <= 0 || h <= 0 || (int64_t)w * h > kMaxTexturePixels) throw bad("bad PNG header");
     if (interlace) throw bad("interlaced PNG is not supported");
     int chan;
     switch (ctype) { case 0: chan = 1; break; case 2: chan = 3; break; case 3: chan = 1; break; case 4: chan = 2; break; case 6: chan = 4; break; default: throw bad("bad PNG colour type"); }
@@ -119,6 +119,7 @@ Image8 decodeTga(const std::vector<uint8_t>& b, const std::string& file)
     const bool rle = type == 10 || type == 11, grey = type == 3 || type == 11;
     if (cmapType != 0 || !(type == 2 || type == 3 || type == 10 || type == 11)) throw bad("unsupported TGA type (true-colour and grey only)");
     if (w <= 0 || h <= 0 || !((grey && bits == 8) || (!grey && (bits == 24 || bits == 32)))) throw bad("unsupported TGA pixel size");
+    if ((int64_t)w * h > kMaxTexturePixels) throw bad("TGA larger than 64 Mpixel");
     const int bytes = bits / 8;
     size_t pos = 18 + (size_t)idLen;
     Image8 im; im.w = w; im.h = h; im.rgb.resize((size_t)w * h * 3);
@@ -155,6 +156,7 @@ ImageF decodeHdr(const std::vector<uint8_t>& b, const std::string& file)
     l = line();
     int w = 0, h = 0;
     if (sscanf(l.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) throw bad("unsupported Radiance orientation");
+    if ((int64_t)w * h > kMaxTexturePixels) throw bad("Radiance picture larger than 64 Mpixel");
     ImageF im; im.w = w; im.h = h; im.rgb.resize((size_t)w * h * 3);
     std::vector<uint8_t> scan((size_t)w * 4);
     auto conv = [](const uint8_t* p, float* o) {

@@ -23,13 +23,14 @@ struct Huff {
     uint8_t vals[256];
     int mincode[17], maxcode[18], valptr[17];
     int16_t look[512];                    // 9-bit prefix -> (length << 8 | value), -1 when the code is longer
-    void build(const uint8_t* bits /*[16]*/, const uint8_t* v, int n)
+    bool build(const uint8_t* bits /*[16]*/, const uint8_t* v, int n)   // false: the code lengths over-subscribe the code space
     {
         memcpy(vals, v, (size_t)n);
         int code = 0, k = 0;
         for (int l = 1; l <= 16; l++) {
             valptr[l] = k; mincode[l] = code;
             code += bits[l - 1]; k += bits[l - 1];
+            if (code > (1 << l)) return false;
             maxcode[l] = bits[l - 1] ? code - 1 : -1;
             code <<= 1;
         }
@@ -42,6 +43,7 @@ struct Huff {
             code <<= 1;
         }
         set = true;
+        return true;
     }
 };
 
@@ -126,7 +128,7 @@ struct Jpeg {
             for (int i = 0; i < 16; i++) { bitsN[i] = (uint8_t)u8(); n += bitsN[i]; }
             if (n > 256) throw bad("bad JPEG Huffman table");
             for (int i = 0; i < n; i++) vals[i] = (uint8_t)u8();
-            ((tc >> 4) ? ac[id] : dc[id]).build(bitsN, vals, n);
+            if (!((tc >> 4) ? ac[id] : dc[id]).build(bitsN, vals, n)) throw bad("bad JPEG Huffman table");
         }
     }
     void sof(int marker)
@@ -136,6 +138,7 @@ struct Jpeg {
         H = u16(); W = u16();
         const int n = u8();
         if (W <= 0 || H <= 0 || (n != 1 && n != 3)) throw bad("unsupported JPEG frame (1 or 3 components)");
+        if ((int64_t)W * H > kMaxTexturePixels) throw bad("JPEG frame larger than 64 Mpixel");
         comps.resize((size_t)n);
         for (Comp& c : comps) {
             c.id = u8(); const int hv = u8(); c.h = hv >> 4; c.v = hv & 15; c.tq = u8();
@@ -156,6 +159,7 @@ struct Jpeg {
         const int t = decode(dc[c.td]);
         if (t > 11) throw bad("bad JPEG DC category");
         c.pred += t ? extend(bits(t), t) : 0;
+        if (c.pred < -32768 || c.pred > 32767) throw bad("JPEG DC value out of range");
         q[0] = (int16_t)c.pred;
         for (int k = 1; k < 64;) {
             const int rs = decode(ac[c.ta]), r = rs >> 4, s = rs & 15;
@@ -172,6 +176,7 @@ struct Jpeg {
                 const int t = decode(dc[c.td]);
                 if (t > 11) throw bad("bad JPEG DC category");
                 c.pred += t ? extend(bits(t), t) : 0;
+                if (c.pred < -32768 || c.pred > 32767) throw bad("JPEG DC value out of range");
                 q[0] = (int16_t)(c.pred * (1 << al));
             } else if (bit()) q[0] = (int16_t)(q[0] | (1 << al));
             return;

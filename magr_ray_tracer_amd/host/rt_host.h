@@ -153,6 +153,7 @@ private:
 // reference: SaveImageF (template/template.cpp:1629-1644) behind Renderer::SaveFrame (renderer.cpp:303-308)
 void SavePNG(const std::string& file, int w, int h, const RtFloat4* data);
 // LoadImageF (template/template.cpp:1613-1627): w*h RGB float triples, top row first (image_io.cpp)
+constexpr int64_t kMaxTexturePixels = int64_t(1) << 26;   // larger headers are treated as corrupt files, not as allocation requests
 std::vector<float> LoadImageF(const std::string& file, int& w, int& h);
 // ITU-T T.81 baseline / progressive Huffman JPEG -> 8-bit RGB, top row first (jpeg_io.cpp)
 void DecodeJpeg(const std::vector<uint8_t>& bytes, const std::string& file, int& w, int& h, std::vector<uint8_t>& rgb);

@@ -394,6 +394,17 @@ def test_load_texture_errors(tmp_path):
     f.write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 64)
     with pytest.raises(Exception, match="JPEG"):
         s.LoadTexture(f, "x")
+    # regression (found by tools/fuzz_image_io.cpp under AddressSanitizer): a DHT segment whose code lengths over-subscribe the code space
+    dht = bytes([0xff, 0xc4, 0x00, 0x16, 0x00, 3] + [0] * 15 + [1, 2, 3])
+    f = tmp_path / "badhuff.jpg"
+    f.write_bytes(b"\xff\xd8" + dht + b"\xff\xd9")
+    with pytest.raises(Exception, match="Huffman"):
+        s.LoadTexture(f, "x")
+    # a frame header that claims 65535 x 65535 pixels is a corrupt file, not an allocation request
+    f = tmp_path / "huge.jpg"
+    f.write_bytes(b"\xff\xd8" + bytes([0xff, 0xc0, 0x00, 0x0b, 8, 0xff, 0xff, 0xff, 0xff, 1, 1, 0x11, 0]) + b"\xff\xd9")
+    with pytest.raises(Exception, match="64 Mpixel"):
+        s.LoadTexture(f, "x")
     f = tmp_path / "cut.png"
     f.write_bytes(_png_bytes(np.zeros((4, 4, 3), dtype=np.int64), 2)[:60])
     with pytest.raises(Exception):
