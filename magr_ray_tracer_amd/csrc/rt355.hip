@@ -479,7 +479,7 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         }
     }
     if (rc != RT_OK) { free_bag(ctx->sceneAllocs); ctx->sceneLoaded = false; return rc; }
-    sc.nLights = nLights; sc.nPrims = nPrims; sc.nBlas = nBlas;
+    sc.nLights = nLights; sc.nPrims = nPrims; sc.nBlas = nBlas; sc.nTex = nTexels;
     // persistent-wavefront traversal: layout 1 and a TLAS whose root is a leaf (one BLAS)
     ctx->persist = ctx->layout == 1 && ctx->cfg.accel == RT_ACCEL_BVH2 && tlas[0].leftRight == 0 && ctx->cfg.extend_variant != 2;
     ctx->persist4 = ctx->layout == 1 && ctx->cfg.accel == RT_ACCEL_BVH4 && tlas[0].leftRight == 0 && ctx->cfg.extend_variant != 2;

@@ -53,7 +53,7 @@ struct DevScene {
     const uint32_t*      rootEntry;  // [nBlas]      encoded root of every instance
     const float4*        shadeRecs;  // [nPrims]     {N.xyz, bits(matIdx | (N.w is -0) << 27 | objType << 28)}: what shade() needs of a 128-B Primitive, in 16 B
     const float4*        quads;      // [nNodes][8]  layout 1 of the BVH4: four child boxes + four encoded child entries (128 B)
-    int32_t nLights, nPrims, nBlas;
+    int32_t nLights, nPrims, nBlas, nTex;
 };
 struct DevQueues {
     // ray queues (compacted), capacity nPix each; bounce b lives in set b & 1 (shade reads one, writes the other)
@@ -850,6 +850,10 @@ RT_FORCEINLINE float4 prim_normal(const RtPrimitive* p, float4 I) // primitives.
     if (type == RT_PRIM_PLANE) return ld4(p->obj.plane.N);
     return ld4(p->obj.triangle.N);
 }
+// Texel `i` of the atlas.  The reference indexes `textures` unchecked (primitives.cl:124,134,145): uv == 1 lands one texel or one row
+// past a texture and a plane with negative u or v up to a whole texture past it - inside the atlas that reads a neighbouring
+// texture's texel (reproduced), past its end it is undefined behaviour.  Here, and in the oracle, texels outside the atlas are zero.
+RT_FORCEINLINE float4 texel(const DevScene& sc, long long i) { return i >= 0 && i < (long long)sc.nTex ? sc.tex[i] : splat(0.0f); }
 RT_FORCEINLINE float4 albedo_of(const DevScene& sc, const RtPrimitive* prim, const RtMaterial* mat, const SRay& ray) // primitives.cl:107-148
 {
     float4 albedo = ld4(mat->color);
@@ -864,18 +868,18 @@ RT_FORCEINLINE float4 albedo_of(const DevScene& sc, const RtPrimitive* prim, con
             if (ux < 0) ux = 1 + ux;
             if (uy < 0) uy = 1 + uy;
             int x = (int)(ux * (float)texW), y = (int)(uy * (float)texH);
-            albedo = sc.tex[texIdx + x + y * texW];
+            albedo = texel(sc, (long long)texIdx + x + (long long)y * texW);
         } else if (type == RT_PRIM_SPHERE) {
             float ux = (float)((1 + atan2f(ray.N.z, ray.N.x) / 3.14159265358979323846) * 0.5);
             float uy = acosf(ray.N.y) / 3.14159265358979323846f;
             int x = (int)(ux * (float)texW), y = (int)(uy * (float)texH);
-            albedo = sc.tex[texIdx + x + y * texW];
+            albedo = texel(sc, (long long)texIdx + x + (long long)y * texW);
         } else {
             float u = fmodf(ray.u, 1.f), v = fmodf(ray.v, 1.f);
             if (u < 0) u = 1 - u;
             if (v < 0) v = 1 - v;
             int x = (int)(u * (float)texW), y = (int)(v * (float)texH);
-            albedo = sc.tex[texIdx + (x + y * texW)];
+            albedo = texel(sc, (long long)texIdx + x + (long long)y * texW);
         }
     }
     return albedo;

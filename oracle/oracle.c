@@ -227,6 +227,9 @@ static f4 prim_normal(const RtPrimitive* p, f4 I) /* primitives.cl:91-105 */
     }
 }
 static inline float fmod1(float x) { return fmodf(x, 1.f); }
+/* The reference indexes `textures` unchecked (primitives.cl:124,134,145); texels outside the atlas are zero here and in the HIP path
+ * (inside the atlas a stray index reads the neighbouring texture's texel, as the reference does). */
+static inline f4 texel(const OrcScene* sc, long long i) { f4 z = { 0, 0, 0, 0 }; return i >= 0 && i < (long long)sc->nTex ? sc->tex[i] : z; }
 static f4 albedo_of(const RtRay* ray, const OrcScene* sc) /* primitives.cl:107-148 */
 {
     const RtPrimitive* prim = &sc->prims[ray->primIdx];
@@ -242,20 +245,20 @@ static f4 albedo_of(const RtRay* ray, const OrcScene* sc) /* primitives.cl:107-1
             if (ux < 0) ux = 1 + ux;
             if (uy < 0) uy = 1 + uy;
             int x = (int)(ux * (float)mat->texW), y = (int)(uy * (float)mat->texH);
-            albedo = sc->tex[mat->texIdx + x + y * mat->texW];
+            albedo = texel(sc, (long long)mat->texIdx + x + (long long)y * mat->texW);
         } break;
         case RT_PRIM_SPHERE: {
             float ux = (float)((1 + atan2f(ray->N.z, ray->N.x) / 3.14159265358979323846) * 0.5); /* atan2pi, double 0.5 */
             float uy = acosf(ray->N.y) / 3.14159265358979323846f;
             int x = (int)(ux * (float)mat->texW), y = (int)(uy * (float)mat->texH);
-            albedo = sc->tex[mat->texIdx + x + y * mat->texW];
+            albedo = texel(sc, (long long)mat->texIdx + x + (long long)y * mat->texW);
         } break;
         case RT_PRIM_PLANE: {
             float u = fmod1(ray->u), v = fmod1(ray->v);
             if (u < 0) u = 1 - u;
             if (v < 0) v = 1 - v;
             int x = (int)(u * (float)mat->texW), y = (int)(v * (float)mat->texH);
-            albedo = sc->tex[mat->texIdx + (x + y * mat->texW)];
+            albedo = texel(sc, (long long)mat->texIdx + x + (long long)y * mat->texW);
         } break;
         }
     }

@@ -720,3 +720,35 @@ def test_fuzz_random_triangle_soups(seed):
     assert np.array_equal(d.get_seeds(), seeds)
     _ctr_equal(d.counters(), e, c)
     d.close()
+
+
+def test_textured_plane_and_stray_texture_indices():
+    """A textured plane seen on both sides of its origin (negative u and v: the reference's lookup then lands up to a whole texture past
+    the texture's window, primitives.cl:137-146) with the texture LAST in the atlas, and a triangle whose uv reach exactly 1: HIP and
+    oracle agree bit for bit, texels outside the atlas read as zero in both (the reference reads out of bounds there)."""
+    from magr_ray_tracer_amd.scene import Scene, material
+    s = Scene()
+    s.AddMaterial("white", material(color=(0.8, 0.8, 0.8)))
+    s.AddMaterial("light", material(color=(1, 1, 1), light=True, emittance=(30, 30, 30)))
+    rng = np.random.default_rng(2)
+    t1 = np.zeros((8, 8, 4), np.float32); t1[..., :3] = rng.random((8, 8, 3))
+    t2 = np.zeros((4, 16, 4), np.float32); t2[..., :3] = rng.random((4, 16, 3))
+    s.AddTexture("first", t1)
+    s.AddTexture("last", t2)
+    s.AddPlane((0, 1, 0), 0.0, "last")
+    s.AddTriangle((-3, 0.5, -2), (3, 0.5, -2), (0, 3, -2), "first", uv0=(0, 0), uv1=(1, 0), uv2=(1, 1))
+    s.AddQuad((-2, 6, -2), (2, 6, -2), (2, 6, 2), (-2, 6, 2), "light", flipNormal=True)
+    s.BuildBLAS(0, 1.0)
+    sa = s.arrays()
+    Wd, Hd = 160, 90
+    cam = scenes.make_camera(Wd, Hd, (0.3, 2.0, 6.0), (0.0, 0.25, 1.0), fov=80.0, aperture=0.0)
+    o = Oracle(sa, Wd, Hd, **DEFAULT)
+    d = Device(Wd, Hd, **DEFAULT)
+    d.upload(sa)
+    acc, seeds, e, c = o.render(cam, 4)
+    d.seed_default()
+    d.render(cam, 4)
+    assert_bits(d.read_accum(), acc, "textured plane")
+    assert np.array_equal(d.get_seeds(), seeds)
+    assert acc[..., :3].sum() > 0
+    d.close()
