@@ -675,7 +675,7 @@ def _png_chunks(b):
 
 
 @pytest.mark.parametrize("seed", range(48))
-def test_fuzz_random_triangle_soups(seed):
+def test_fuzz_random_triangle_soups(seed, big=False):
     """Random triangle soups (slivers, overlapping and coplanar triangles, mirrors, several lights of different size), random camera,
     random kernel variant and SBVH alpha, random frame size: accumulator, RNG state and work counters bit-exact against the oracle."""
     from magr_ray_tracer_amd.scene import Scene, material
@@ -704,6 +704,8 @@ def test_fuzz_random_triangle_soups(seed):
     s.BuildBLAS(0, alpha=float(rng.choice([1.0, 1e-5, 0.0])))
     sa = s.arrays()
     Wd, Hd = int(rng.integers(17, 200)), int(rng.integers(9, 120))
+    if big:   # tools/deep_fuzz.py: long queues (persistent-wavefront branch with RT355_TUNE=...,1; several super-tiles in k_shade)
+        Wd, Hd = int(rng.integers(300, 520)), int(rng.integers(200, 300))
     v = dict(DEFAULT, accel=int(rng.integers(0, 2)), shading=int(rng.integers(0, 2)), sampling=int(rng.integers(0, 2)),
              russian_roulette=bool(rng.integers(0, 2)), filter_fireflies=bool(rng.integers(0, 2)))
     org = rng.random(3) * 6 - 3 + np.array([0, 0, 9.0])

@@ -1,0 +1,27 @@
+"""One-off deep fuzz on the GPU box: the randomized parity test of tests/test_gpu_parity.py over many more seeds."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_parity as T  # noqa: E402
+
+first, count = int(sys.argv[1]), int(sys.argv[2])
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
+if big:
+    os.environ["RT355_TUNE"] = "64,20,6,8,1"   # one workgroup per CU: queues above 65,536 rays take the persistent branch
+bad = []
+t = time.time()
+for seed in range(first, first + count):
+    try:
+        T.test_fuzz_random_triangle_soups(seed, big)
+    except AssertionError as e:
+        bad.append((seed, str(e)[:200]))
+        print("MISMATCH seed", seed, str(e)[:300], flush=True)
+    except Exception as e:   # builder / upload errors are findings too
+        bad.append((seed, repr(e)[:200]))
+        print("ERROR seed", seed, repr(e)[:300], flush=True)
+print(f"deep fuzz: seeds {first}..{first + count - 1}, {len(bad)} failures, {time.time() - t:.1f} s")
+sys.exit(1 if bad else 0)
