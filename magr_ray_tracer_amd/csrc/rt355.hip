@@ -54,7 +54,7 @@ struct RtCtx {
     bool shadeRun[RT_MAX_BOUNCES + 1] = {};           // shade(b) launched since the last k_begin_frame
     bool generated = false;                           // generate launched since the last k_begin_frame
     int stackEntries = RT_BVH2_STACK, persistGrid = 0, persistGridConnect = 0;
-    PersistTune tune{ 64, 20, 6, 8 }, tuneConnect{ 128, 32, 6, 8 };   // measured optima (profiles/r01_persist_tuning.log, tools/tune_connect.sh)
+    PersistTune tune{ 112, 24, 6, 8 }, tuneConnect{ 128, 32, 6, 8 }, tune4{ 64, 20, 6, 8 };   // extend (BVH2), connect, extend (BVH4): measured optima (tools/tune_extend.sh, tune_connect.sh, tune_persist.sh)
     float4* dPostF = nullptr; uchar4* dPostB = nullptr;   // post-processing outputs (lazy)
     int32_t* dSteps = nullptr;   // per-ray `steps` buffer, only bound while rt_debug_enable_steps is on
     int shadeGrid = 1024;   // workgroups of k_shade (what the CUs hold at once; the kernel does not depend on it); set in rt_create
@@ -495,7 +495,7 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner,leafK[,blocksPerCU]" (tuning aid)
             int a = 0, b = 0, c = 0, l = 0, d = 0;
             int k = sscanf(t, "%d,%d,%d,%d,%d", &a, &b, &c, &l, &d);
-            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = ctx->tuneConnect = PersistTune{ a, b, c, l };
+            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = ctx->tuneConnect = ctx->tune4 = PersistTune{ a, b, c, l };
             if (k == 5 && d > 0) ctx->persistGrid = ctx->persistGridConnect = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount);
         }
         if (const char* t = getenv("RT355_TUNE_CONNECT")) { // same fields, connect launches only
@@ -601,7 +601,7 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
     }
     // bounce 0: primary rays are coherent and finish together, refilling buys nothing -> one ray per lane
     if (ctx->persist4)
-        LAUNCH(ctx, ST_EXTEND, (k_trace_persist4<false>), bounce > 0 ? dim3(ctx->persistGrid) : grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+        LAUNCH(ctx, ST_EXTEND, (k_trace_persist4<false>), bounce > 0 ? dim3(ctx->persistGrid) : grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune4);
     else if (ctx->persist && (bounce > 0 || ctx->cfg.extend_variant == 3))
         LAUNCH(ctx, ST_EXTEND, (k_trace_persist<false>), dim3(ctx->persistGrid), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
     else if (ctx->persist && ctx->cfg.extend_variant != 5)
