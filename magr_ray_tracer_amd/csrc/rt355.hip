@@ -132,10 +132,11 @@ static RtCtx::Ev& ev_slot(RtCtx* c, int stage)
     c->evUsed++;
     return e;
 }
-#define LAUNCH(ctx, stage, kernel, grid, shmem, ...) do { \
-        if (ev_on(ctx, stage)) { RtCtx::Ev& e_ = ev_slot(ctx, stage); hipExtLaunchKernelGGL(kernel, grid, dim3(kBlock), (uint32_t)(shmem), (ctx)->stream, e_.a, e_.b, 0, __VA_ARGS__); } \
-        else hipLaunchKernelGGL(kernel, grid, dim3(kBlock), shmem, (ctx)->stream, __VA_ARGS__); \
+#define LAUNCHB(ctx, stage, kernel, grid, block, shmem, ...) do { \
+        if (ev_on(ctx, stage)) { RtCtx::Ev& e_ = ev_slot(ctx, stage); hipExtLaunchKernelGGL(kernel, grid, dim3(block), (uint32_t)(shmem), (ctx)->stream, e_.a, e_.b, 0, __VA_ARGS__); } \
+        else hipLaunchKernelGGL(kernel, grid, dim3(block), shmem, (ctx)->stream, __VA_ARGS__); \
     } while (0)
+#define LAUNCH(ctx, stage, kernel, grid, shmem, ...) LAUNCHB(ctx, stage, kernel, grid, kBlock, shmem, __VA_ARGS__)
 static void ev_collect(RtCtx* c) // call after a stream sync
 {
     for (auto& e : c->evPool) if (e.stage >= 0) ev_account(c, e);
@@ -171,11 +172,11 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     {   // k_shade: as many workgroups as the CUs hold at once.  Its ordered scan does not depend on that (tiles go by ticket to
         // running workgroups), so the size only matters for speed.  The occupancy query knows the VGPR, LDS and wave-slot limits
         // but not the SGPR file: 256-thread workgroups are admitted up to min(query, 8, 800 / (ceil16(sgprs) + 16)) per CU
-        // (MI355X_MICROARCH.md, residency) = 6 for any kernel (<= 112 SGPRs), 7 up to 96 SGPRs.  k_shade: 4 (registers, 39 KB LDS).
+        // (MI355X_MICROARCH.md, residency) = 6 for any kernel (<= 112 SGPRs), 7 up to 96 SGPRs.  k_shade: 2 workgroups of 512 threads (registers, 78 KB LDS).
         hipDeviceProp_t prop; int perCU = 0;
         HIPCHK(hipGetDeviceProperties(&prop, c.device));
-        if (c.shading == RT_SHADING_NEE) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<true>, kBlock, 0));
-        else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<false>, kBlock, 0));
+        if (c.shading == RT_SHADING_NEE) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<true>, kTile, 0));
+        else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<false>, kTile, 0));
         perCU = std::min(perCU, kAdmitAnySgpr);
         ctx->shadeGrid = prop.multiProcessorCount * std::max(1, perCU);
         if (const char* g = getenv("RT355_SHADE_PER_CU")) { int v = atoi(g); if (v > 0 && v <= 16) ctx->shadeGrid = prop.multiProcessorCount * v; }   // tuning / over-subscription tests
@@ -632,11 +633,11 @@ extern "C" int rt_stage_shade(RtCtx* ctx, int32_t bounce)
         HIPCHK(hipMemsetAsync(ctx->q.supAcc[bounce & 1], 0, sizeof(unsigned long long) * (nTiles / 64 + 2), ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->q.shadeTicket + (size_t)bounce * kTicketClasses * kTicketStride, 0, sizeof(int32_t) * (size_t)kTicketClasses * kTicketStride, ctx->stream));
     }
-    const dim3 sg((unsigned)std::max(1, std::min(ctx->shadeGrid, (ctx->nPix + kBlock - 1) / kBlock)));
+    const dim3 sg((unsigned)std::max(1, std::min(ctx->shadeGrid, (ctx->nPix + kTile - 1) / kTile)));
     if (ctx->cfg.shading == RT_SHADING_NEE)
-        LAUNCH(ctx, ST_SHADE, k_shade<true>, sg, 0, ctx->sc, ctx->q, ctx->var, bounce);
+        LAUNCHB(ctx, ST_SHADE, k_shade<true>, sg, kTile, 0, ctx->sc, ctx->q, ctx->var, bounce);
     else
-        LAUNCH(ctx, ST_SHADE, k_shade<false>, sg, 0, ctx->sc, ctx->q, ctx->var, bounce);
+        LAUNCHB(ctx, ST_SHADE, k_shade<false>, sg, kTile, 0, ctx->sc, ctx->q, ctx->var, bounce);
     ctx->shadeRun[bounce] = true;
     HIPCHK(hipGetLastError());
     return RT_OK;

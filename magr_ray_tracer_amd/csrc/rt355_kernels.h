@@ -78,7 +78,7 @@ struct DevQueues {
     int32_t nPix, firstPixel, width, height;
 };
 // k_shade hands its tiles out through kTicketClasses counters (class c serves tiles c, c + K, c + 2K, ...), 4 KB apart so that
-// they sit in different memory channels: one counter would take all ~8,100 tickets of a 1080p launch at the chip's ~88 same-address
+// they sit in different memory channels: one counter would take all ~4,000 tickets of a 1080p launch at the chip's ~88 same-address
 // atomics per microsecond
 static constexpr int kTicketClasses = 32, kTicketStride = 1024, kCursorWords = 2 * (RT_MAX_BOUNCES + 2);
 struct DevVariant { int32_t shading, sampling, accel, rr, fireflies, maxBounces; };
@@ -1027,12 +1027,13 @@ RT_FORCEINLINE float4 shade_hit(const DevScene& sc, const DevVariant& var, SRay&
 // Tile status word of the decoupled look-back scan: [63:62] flag (0 empty, 1 aggregate, 2 inclusive
 // prefix), [61:31] extension-ray count, [30:0] shadow-ray count.  Flag and payload travel in ONE 8-byte
 // word written/read with agent-scope atomics (L2-coherent across XCDs), so no separate fence is needed.
+static constexpr int kTile = 512;   // queue slots per tile = threads of a k_shade workgroup (a multiple of the 256 slots k_generate arms per workgroup)
 static constexpr unsigned long long kTileAgg = 1ull << 62, kTilePrefix = 2ull << 62, kTilePrefixZero = 2ull << 62;
 RT_FORCEINLINE unsigned long long tile_pack(unsigned long long flag, uint32_t e, uint32_t s) { return flag | ((unsigned long long)e << 31) | (unsigned long long)s; }
 RT_FORCEINLINE uint32_t tile_ext(unsigned long long v) { return (uint32_t)((v >> 31) & 0x7fffffffull); }
 RT_FORCEINLINE uint32_t tile_sh(unsigned long long v) { return (uint32_t)(v & 0x7fffffffull); }
 
-// Persistent workgroups take tiles (256 consecutive queue slots) by ticket (see the kernel).  Publishing a tile's counts waits
+// Persistent workgroups take tiles (kTile consecutive queue slots) by ticket (see the kernel).  Publishing a tile's counts waits
 // for nothing; closing a super-tile and resolving a tile's position only wait for words of smaller tile / super-tile ids.
 // Bounded wait on a status word: every spin in this library has an upper bound (~seconds), after which the kernel raises
 // q.fault and carries on with a zero payload instead of hanging the GPU; the host reports RT_E_DEVICE.
@@ -1052,14 +1053,14 @@ RT_FORCEINLINE unsigned long long wait_word(const unsigned long long* p, unsigne
 }
 
 template <bool NEE>
-__global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, DevVariant var, int bounce)
+__global__ __launch_bounds__(kTile, 4) void k_shade(DevScene sc, DevQueues q, DevVariant var, int bounce)
 {
     // [2]: a tile's outputs are written one tile late (see the loop), so the counts and the shadow records of two tiles are alive
-    __shared__ uint32_t sWaveE[2][kBlock / 64], sWaveS[2][kBlock / 64], sBaseE, sBaseS;
+    __shared__ uint32_t sWaveE[2][kTile / 64], sWaveS[2][kTile / 64], sBaseE, sBaseS;
     // Survivors wait in LDS (104 B per lane) while the ordered scan resolves, instead of in ~28 registers: the
     // kernel's occupancy is set by the shading code, not by values that are merely parked across the scan.
-    __shared__ float4 sExtO[kBlock], sExtD[kBlock], sExtI[kBlock], sShA[2][kBlock], sShB[2][kBlock], sShC[2][kBlock];
-    __shared__ uint2 sExtM[kBlock];
+    __shared__ float4 sExtO[kTile], sExtD[kTile], sExtI[kTile], sShA[2][kTile], sShB[2][kTile], sShC[2][kTile];
+    __shared__ uint2 sExtM[kTile];
     const int cur = bounce & 1, nxt = cur ^ 1;
     unsigned long long* state = q.tile[cur];
     unsigned long long* const* super = q.super;
@@ -1068,7 +1069,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, D
         if (blockIdx.x == 0 && threadIdx.x == 0) { q.nRays[bounce + 1] = 0; q.nShadow[bounce + 1] = q.nShadow[bounce]; }
         return;
     }
-    const uint32_t numTiles = (uint32_t)((n + kBlock - 1) / kBlock);
+    const uint32_t numTiles = (uint32_t)((n + kTile - 1) / kTile);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int shadowBase = q.nShadow[bounce];
 
@@ -1078,7 +1079,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, D
         if (wave == 0) {
             uint32_t aggE = 0, aggS = 0;
 #pragma unroll
-            for (int w = 0; w < kBlock / 64; w++) { aggE += sWaveE[pp][w]; aggS += sWaveS[pp][w]; }
+            for (int w = 0; w < kTile / 64; w++) { aggE += sWaveE[pp][w]; aggS += sWaveS[pp][w]; }
             // Level 1 of the ordered scan: the counts of the earlier tiles of the own super-tile (one 64-lane read) plus the
             // inclusive prefix of the previous super-tile (level 2, resolved by whichever workgroup closed that super-tile).
             const uint32_t sup = t >> 6, inSup = t & 63u;
@@ -1126,7 +1127,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, D
     // the queue entries of the NEXT tile are fetched before the previous tile is drained, so their latency hides behind the drain
     struct TileIn { float4 hit, O, D, inten; uint2 meta; uint32_t seed; };
     auto fetch = [&](uint32_t t, TileIn& in) {
-        const int j = (int)t * kBlock + threadIdx.x;
+        const int j = (int)t * kTile + threadIdx.x;
         if (t < numTiles && j < n) {
             in.hit = q.hit[j]; in.meta = q.meta[cur][j]; in.O = q.O[cur][j]; in.D = q.D[cur][j]; in.inten = q.inten[cur][j]; in.seed = q.seeds[j];
         }
@@ -1148,7 +1149,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, D
     TileIn in;
     fetch(tile, in);
     for (; tile < numTiles; par ^= 1) {
-        const int i = (int)tile * kBlock + threadIdx.x;
+        const int i = (int)tile * kTile + threadIdx.x;
         if (threadIdx.x == 0) {
             q.tile[nxt][1 + tile] = 0ull;     // arm shade(bounce+1)'s scan (its queue is never longer)
             tkNext = (uint32_t)atomicAdd(ticket, 1);
@@ -1205,7 +1206,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_shade(DevScene sc, DevQueues q, D
         if (wave == 0) {
             uint32_t aggE = 0, aggS = 0;
 #pragma unroll
-            for (int w = 0; w < kBlock / 64; w++) { aggE += sWaveE[par][w]; aggS += sWaveS[par][w]; }
+            for (int w = 0; w < kTile / 64; w++) { aggE += sWaveE[par][w]; aggS += sWaveS[par][w]; }
             const uint32_t sup = tile >> 6;
             unsigned long long acc = 0ull;
             if (lane == 0) {
