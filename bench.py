@@ -3,11 +3,12 @@
 sponza 1080p 256spp").
 
 A step = one Renderer::RayTrace() frame (1 sample per pixel) of the sponza-class scene at 1920x1080:
-generate, 7 x (extend, shade, compact), connect.  `value` = W*H*steps*N / t / 1e6 — the reference's own
+generate, 7 x (extend, shade), connect.  `value` = W*H*steps*N / t / 1e6 — the reference's own
 "Mrays/s" definition (primary samples per second, src/renderer.cpp:60-62) summed over all ranks.
-Scene, BVH and seeds are resident in HBM before the timed region.  N > 1: one process per GPU
-(torch.distributed / RCCL), samples partitioned across ranks, one all_reduce(SUM) of the accumulator
-inside the timed region.
+Scene, BVH and seeds are resident in HBM before the timed region.  The samples are partitioned twice (magr_ray_tracer_amd/dist.py):
+across the N ranks (one process per GPU, torch.distributed / RCCL, one all_reduce(SUM) of the accumulator inside the timed
+region) and, inside a GPU, across `--lanes` independent contexts whose frames are interleaved so that the tails of one context's
+launches are filled by the other's kernels; a rank's `steps` frames are shared out over its lanes.
 """
 import argparse
 import json
@@ -40,6 +41,7 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0, help="sponza-class tessellation (1.0 = ~262k triangles)")
     ap.add_argument("--accel", choices=["bvh2", "bvh4"], default="bvh2")
     ap.add_argument("--shard", choices=["samples", "bands"], default="samples")
+    ap.add_argument("--lanes", type=int, default=2, help="independent sample streams per GPU whose frames overlap (samples plan only; 1 = one context)")
     ap.add_argument("--extend-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stage launches with HIP events")
@@ -65,20 +67,30 @@ def main():
     s, view = scenes.sponza_class(args.detail)
     sa = s.arrays(bvh4=bool(accel))
     build_s = time.time() - t0
-    p = rdist.plan(args.shard, W, H, rank, world)
+    lanes = max(1, args.lanes) if args.shard == "samples" else 1
     # timed region: HIP events around the extend launches only (the roofline's kernel); the per-stage table comes from a short
     # fully-bracketed pass afterwards, outside the timed region
-    dev = Device(W, H, y0=p["y0"], y1=p["y1"], accel=accel, device=local, profile=0 if args.no_profile else 1,
-                 extend_variant=args.extend_variant)
-    dev.upload(sa)
     cam = scenes.camera_for(view, W, H)
+    accums = [torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}") for _ in range(lanes)]
+
+    def make_device(m):
+        p = rdist.plan(args.shard, W, H, rank, world, m, lanes)
+        d = Device(W, H, y0=p["y0"], y1=p["y1"], accel=accel, device=local, profile=0 if args.no_profile else 1,
+                   extend_variant=args.extend_variant)
+        d.upload(sa)
+        d.bind_accum(accums[m])
+        return d
+
+    def seeds_for(m):
+        p = rdist.plan(args.shard, W, H, rank, world, m, lanes)
+        seeds = np.zeros(p["seed_count"], np.uint32)
+        _seed_stream(seeds, p["seed_first"])
+        return seeds
+
+    group = rdist.Lanes(lanes, make_device, seeds_for)
+    dev = group.devs[0]
     cam["focalLength"] = dev.focus(W // 2, H // 2, cam)
-    from magr_ray_tracer_amd import _lib
-    seeds = np.zeros(p["seed_count"], np.uint32)
-    _seed_stream(seeds, p["seed_first"])
-    dev.set_seeds(seeds)
-    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}")
-    dev.bind_accum(accum)
+    accum = accums[0]
 
     def barrier():
         torch.cuda.synchronize()
@@ -86,23 +98,30 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
+    def reduce_all():
+        for a in accums[1:]:      # the rank's accumulator = sum of its lanes in lane order ...
+            accum.add_(a)
+        rdist.reduce_accumulator(accum)   # ... then the one exchange step across ranks
+
     # ---- warmup ------------------------------------------------------------------------------------------
     if args.warmup > 0:
-        dev.render(cam, args.warmup)
-        dev.synchronize()
-        rdist.reduce_accumulator(accum)
-    dev.reset()
-    dev.synchronize()
-    dev.reset_counters()
-    dev.reset_stage_times()
-    accum.zero_()
+        group.render(cam, args.warmup * lanes)
+        group.synchronize()
+        reduce_all()
+    for d in group.devs:
+        d.reset()
+        d.synchronize()
+        d.reset_counters()
+        d.reset_stage_times()
+    for a in accums:
+        a.zero_()
     barrier()
 
-    # ---- timed region: exactly `steps` frames + the one accumulator reduction ----------------------------------
+    # ---- timed region: exactly `steps` frames (shared out over the lanes) + the accumulator reduction -----------
     t0 = time.perf_counter()
-    dev.render(cam, args.steps)
-    dev.synchronize()
-    rdist.reduce_accumulator(accum)
+    group.render(cam, args.steps)
+    group.synchronize()
+    reduce_all()
     barrier()
     dt = time.perf_counter() - t0
     checksum = float(accum[..., :3].sum().item())
@@ -111,10 +130,15 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    ctr = dev.counters()
-    st = dev.stage_times()
+    ctr, st = {}, {}
+    for d in group.devs:          # totals over the lanes
+        for k, v in d.counters().items():
+            ctr[k] = ctr.get(k, 0) + v
+        for k, v in d.stage_times().items():
+            st[k] = st.get(k, 0) + v
     stage_tab, con_ms, con_launches, con_bytes = {}, 0.0, 0, 0
-    if not args.no_profile and rank == 0:   # untimed: 16 more frames with every stage bracketed
+    single = {}
+    if not args.no_profile and rank == 0:   # untimed: 16 more frames of ONE context with every stage bracketed (kernels undisturbed)
         dev.set_profile(2)
         dev.reset_stage_times()
         c0 = dev.counters()
@@ -123,7 +147,12 @@ def main():
         st2, c1 = dev.stage_times(), dev.counters()
         stage_tab = {k[:-3]: round(st2[k] / 16, 4) for k in st2 if k.endswith("_ms") and k != "compact_ms"}
         con_ms, con_launches = st2["connect_ms"], st2["connect_launches"]
-        con_bytes = extend_bytes({k: c1[k] - c0[k] for k in c1}, accel, "connect")
+        dctr = {k: c1[k] - c0[k] for k in c1}
+        con_bytes = extend_bytes(dctr, accel, "connect")
+        e_ms = st2["extend_ms"] / max(st2["extend_launches"], 1)
+        e_gbs = extend_bytes(dctr, accel) / max(st2["extend_launches"], 1) / (e_ms * 1e-3) / 1e9 if e_ms > 0 else 0.0
+        single = {"achieved": round(e_gbs, 2), "frac": round(e_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(e_ms, 5),
+                  "note": "the same kernel with the GPU to itself (one context, 16 untimed frames after the timed region)"}
     samples = W * H * args.steps * (world if args.shard == "samples" else 1)
     value = samples / dt / 1e6
 
@@ -149,8 +178,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"sponza-class procedural atrium ({len(sa.prims)} prims, SAH {args.accel.upper()}, "
                                    f"{len(sa.bvh2)} nodes) {W}x{H}, NEE+cosine+RR+firefly, 7 bounces; step = 1 spp frame, "
-                                   f"{args.steps} spp timed per GPU (BASELINE config 3 = 256 spp)",
-                       "shard": args.shard, "triangles": int(len(sa.prims)), "extend_variant": args.extend_variant},
+                                   f"{args.steps} spp timed per GPU (BASELINE config 3 = 256 spp) as {lanes} interleaved sample stream(s)",
+                       "shard": args.shard, "lanes": lanes, "triangles": int(len(sa.prims)), "extend_variant": args.extend_variant},
             "traced_mrays_per_s": round(traced * (world if args.shard == "samples" else 1) / dt / 1e6, 2),
             "rays_per_step": {"extend": ctr["extend_rays"] // args.steps, "connect": ctr["connect_rays"] // args.steps},
             "roofline": {"bound": "hbm", "kernel": "extend (k_trace_persist<false>)", "achieved": round(ext_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -158,7 +187,10 @@ def main():
                          "algorithmic_bytes_per_launch": int(ext_bytes), "avg_launch_ms": round(ext_ms, 5),
                          "launches": st["extend_launches"],
                          "note": "achieved = algorithmic bytes (SURVEY 8(d) formula x device counters) / HIP-event time; node and triangle data "
-                                 "(~30 MB) are served from L1/L2/Infinity Cache, so achieved may exceed the HBM peak while `traffic` (PMC, DRAM side) stays far below it",
+                                 "(~21 MB) are served from L1/L2/Infinity Cache, so achieved may exceed the HBM peak while `traffic` (PMC, DRAM side) stays "
+                                 "far below it.  With lanes > 1 the launches of different sample streams share the GPU, so a launch takes longer than it "
+                                 "does alone (`single_stream`) while the frame rate goes up",
+                         "single_stream": single,
                          "per_ray": {"node_visits": round(ctr["extend_node_visits"] / max(ctr["extend_rays"], 1), 2),
                                      "prim_tests": round(ctr["extend_prim_tests"] / max(ctr["extend_rays"], 1), 2)}},
             "connect_roofline": {"achieved": round(con_gbs, 2), "frac": round(con_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(con_ms, 5)},
@@ -168,7 +200,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sa, cam, W, H, accel)
         print(json.dumps(out), flush=True)
-    dev.close()
+    group.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -701,7 +701,7 @@ static int check_fault(RtCtx* ctx) // after a stream sync: did a bounded device-
     HIPCHK(hipMemcpy(&f, ctx->q.fault, sizeof f, hipMemcpyDeviceToHost));
     if (f) {
         (void)hipMemset(ctx->q.fault, 0, sizeof f);
-        return fail(RT_E_DEVICE, "device fault %d: a bounded wait of the ordered scan in k_shade expired (results of this render are invalid)", f);
+        return fail(RT_E_DEVICE, "device fault 0x%08x: a bounded wait of the ordered scan in k_shade expired (results of this render are invalid)", (unsigned)f);
     }
     return RT_OK;
 }

@@ -77,10 +77,12 @@ struct DevQueues {
     unsigned long long* ctrConnect; // [gridMax][5]
     int32_t nPix, firstPixel, width, height;
 };
-// k_shade hands its tiles out through kTicketClasses counters (class c serves tiles c, c + K, c + 2K, ...), 4 KB apart so that
-// they sit in different memory channels: one counter would take all ~4,000 tickets of a 1080p launch at the chip's ~88 same-address
-// atomics per microsecond
-static constexpr int kTicketClasses = 32, kTicketStride = 1024, kCursorWords = 2 * (RT_MAX_BOUNCES + 2);
+// k_shade hands its tiles out by ticket.  ONE counter: any running workgroup draws the smallest tile not drawn yet, so the ordered scan
+// depends on nothing but "some workgroup of the launch is running".  (A counter per class of workgroups - class = blockIdx mod 32,
+// tiles c, c + 32, ... - takes the tickets off one memory channel and was 5 % faster for k_shade, but workgroups go to the XCDs
+// round-robin, so an XCD then serves only 4 of the 32 classes, and two processes with two contexts each dead-locked within a few
+// frames: four partially resident k_shade grids, each holding the XCD another one needed.  tests: test_two_processes_with_two_lanes_...)
+static constexpr int kTicketClasses = 1, kTicketStride = 1024, kCursorWords = 2 * (RT_MAX_BOUNCES + 2);
 struct DevVariant { int32_t shading, sampling, accel, rr, fireflies, maxBounces; };
 
 // meta.y bit layout
@@ -1038,13 +1040,13 @@ RT_FORCEINLINE uint32_t tile_sh(unsigned long long v) { return (uint32_t)(v & 0x
 // Bounded wait on a status word: every spin in this library has an upper bound (~seconds), after which the kernel raises
 // q.fault and carries on with a zero payload instead of hanging the GPU; the host reports RT_E_DEVICE.
 static constexpr uint32_t kSpinLimit = 1u << 22;   // x ~1-2 us per poll: several seconds
-RT_FORCEINLINE unsigned long long wait_word(const unsigned long long* p, unsigned long long needFlag /*0: any non-empty, 2: prefix*/, int32_t* fault)
+RT_FORCEINLINE unsigned long long wait_word(const unsigned long long* p, unsigned long long needFlag /*0: any non-empty, 2: prefix*/, int32_t* fault, int32_t what = 1)
 {
     unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t spins = 0;
     while (needFlag == 2ull ? (v >> 62) != 2ull : (v >> 62) == 0ull) {
         // give up when the bound is reached - or when another wave already has: once the flag is up the launch's results are void
-        if (++spins > kSpinLimit || ((spins & 1023u) == 0u && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { *fault = 1; return kTilePrefixZero; }
+        if (++spins > kSpinLimit || ((spins & 1023u) == 0u && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { atomicCAS(fault, 0, what); return kTilePrefixZero; }   // `what`: which word was waited for (diagnostic)
         // back off: a few quick polls, then ~1 us naps, so that thousands of waiting waves do not flood the L2 with polls
         if (spins < 4) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(32);
         v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1085,8 +1087,8 @@ __global__ __launch_bounds__(kTile, 4) void k_shade(DevScene sc, DevQueues q, De
             const uint32_t sup = t >> 6, inSup = t & 63u;
             // lanes 0..inSup-1 fetch the earlier tiles' words, lane 63 the previous super-tile's: one round trip for both levels
             unsigned long long v = 0ull;
-            if ((uint32_t)lane < inSup) v = wait_word(&state[1 + (sup << 6) + (uint32_t)lane], 0ull, q.fault);
-            else if (lane == 63 && sup > 0) v = wait_word(&super[cur][sup - 1], 2ull, q.fault);
+            if ((uint32_t)lane < inSup) v = wait_word(&state[1 + (sup << 6) + (uint32_t)lane], 0ull, q.fault, 0x10000000 | (int32_t)((sup << 6) + (uint32_t)lane));
+            else if (lane == 63 && sup > 0) v = wait_word(&super[cur][sup - 1], 2ull, q.fault, 0x20000000 | (int32_t)(sup - 1));
             const unsigned long long vp = __shfl(v, 63, 64);
             const uint32_t preE = sup > 0 ? tile_ext(vp) : 0u, preS = sup > 0 ? tile_sh(vp) : 0u;   // inclusive prefix of super-tiles [0, sup)
             uint32_t inE = (uint32_t)lane < inSup ? tile_ext(v) : 0u, inS = (uint32_t)lane < inSup ? tile_sh(v) : 0u;   // counts of tiles [64*sup, t)
@@ -1132,12 +1134,11 @@ __global__ __launch_bounds__(kTile, 4) void k_shade(DevScene sc, DevQueues q, De
             in.hit = q.hit[j]; in.meta = q.meta[cur][j]; in.O = q.O[cur][j]; in.D = q.D[cur][j]; in.inten = q.inten[cur][j]; in.seed = q.seeds[j];
         }
     };
-    // Tiles are handed out by ticket to workgroups that are RUNNING.  Class c = blockIdx.x mod K owns tiles c, c + K, c + 2K, ... and
-    // hands them out in increasing order, one ticket = one tile (K = kTicketClasses counters instead of one: see there).  What a tile
-    // waits for are words of smaller tile / super-tile ids; the smallest unpublished tile is either held by a running workgroup, which
-    // publishes before it waits for anything newer, or is the next ticket of its class, which a running workgroup of that class draws
-    // as soon as its own (smaller, hence published) tile is done.  So the scan needs one running workgroup per class - K workgroups
-    // with consecutive ids - not a co-resident grid, and it also gets through when the GPU is shared with other work.
+    // Tiles are handed out by ticket to workgroups that are RUNNING, in increasing order (kTicketClasses = 1: one counter, see there;
+    // the class arithmetic below is kept general).  What a tile waits for are words of smaller tile / super-tile ids; the smallest
+    // unpublished tile is either held by a running workgroup, which publishes before it waits for anything newer, or it is the next
+    // ticket, which any running workgroup draws as soon as its own (smaller, hence published) tile is done.  So the scan needs no
+    // co-resident grid and also gets through when the GPU is shared with other contexts and processes.
     __shared__ uint32_t sTicket;
     const uint32_t cls = blockIdx.x % (uint32_t)kTicketClasses;
     int32_t* ticket = q.shadeTicket + ((size_t)bounce * kTicketClasses + cls) * kTicketStride;
@@ -1230,7 +1231,7 @@ __global__ __launch_bounds__(kTile, 4) void k_shade(DevScene sc, DevQueues q, De
                     for (;;) {
                         const int tt = top - lane;
                         unsigned long long v = kTilePrefix;
-                        if (tt >= 0) v = wait_word(&super[cur][tt], 0ull, q.fault);
+                        if (tt >= 0) v = wait_word(&super[cur][tt], 0ull, q.fault, 0x30000000 | tt);
                         const unsigned long long isPre = __ballot((v >> 62) == 2ull);
                         const int stop = isPre ? __ffsll((long long)isPre) - 1 : 64;
                         uint32_t e = lane <= stop ? tile_ext(v) : 0u, s2 = lane <= stop ? tile_sh(v) : 0u;

@@ -83,3 +83,24 @@ def test_two_ranks_gloo_reduce(tmp_path, shard):
         # zero-padded reduce == gather of the bands
         p0, p1 = rdist.plan(shard, W, H, 0, 2), rdist.plan(shard, W, H, 1, 2)
         assert got[p0["y0"]:p0["y1"]].any() and got[p1["y0"]:p1["y1"]].any()
+
+
+def test_lanes_are_virtual_ranks_of_the_sample_plan():
+    """Lanes partition the samples once more inside a rank: (rank, lane) takes the seed slice of virtual rank rank*lanes + lane, the slices
+    of all (rank, lane) pairs tile the stream without gap or overlap, and `steps` frames are shared out exactly."""
+    W, H, world, lanes = 7, 5, 3, 2
+    P = W * H
+    seen = []
+    for r in range(world):
+        for m in range(lanes):
+            p = rdist.plan("samples", W, H, r, world, m, lanes)
+            assert (p["y0"], p["y1"], p["seed_count"]) == (0, H, P)
+            seen.append(p["seed_first"])
+    assert seen == [v * P for v in range(world * lanes)]
+    assert rdist.plan("samples", W, H, 2, world) == rdist.plan("samples", W, H, 2, world, 0, 1)
+    with pytest.raises(ValueError):
+        rdist.plan("bands", W, H, 0, world, 0, 2)
+    for frames in (0, 1, 5, 256):
+        for n in (1, 2, 3):
+            parts = rdist.lane_frames(frames, n)
+            assert sum(parts) == frames and max(parts) - min(parts) <= 1 and parts == sorted(parts, reverse=True)

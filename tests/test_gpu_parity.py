@@ -600,6 +600,43 @@ def _render_crc(args):
     return out
 
 
+def _render_lanes_crc(args):
+    """Child process: `lanes` contexts of dist.Lanes render `frames` frames of the 1080p bench scene; checksum of the summed accumulator."""
+    lanes, frames = args
+    import numpy as np
+    from magr_ray_tracer_amd import dist as rdist, scenes
+    from magr_ray_tracer_amd.renderer import Device
+    from oracle.oracle_py import seed_stream
+    Wd, Hd = 1920, 1080
+    s, view = scenes.sponza_class(1.0)
+    sa = s.arrays()
+
+    def make(m):
+        d = Device(Wd, Hd, **DEFAULT)
+        d.upload(sa)
+        return d
+    g = rdist.Lanes(lanes, make, lambda m: seed_stream(m * Wd * Hd, Wd * Hd))
+    g.render(scenes.camera_for(view, Wd, Hd), frames)
+    g.synchronize()                                   # raises RtError on a device fault
+    out = int(g.read_accum().view(np.uint32).astype(np.uint64).sum())
+    g.close()
+    return out
+
+
+def test_two_processes_with_two_lanes_each_share_the_gpu():
+    """Regression: with one ticket counter per class of workgroups (class = blockIdx mod 32) two processes of two contexts each
+    dead-locked k_shade's scan within a few frames - workgroups go to the XCDs round-robin, so an XCD serves only 4 of 32 classes, and
+    four partially resident k_shade grids could each hold the XCD another one needed.  With ONE counter any running workgroup draws the
+    smallest undrawn tile and nothing depends on which workgroups are resident."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(1) as pool:
+        solo = pool.map(_render_lanes_crc, [(2, 48)])[0]
+    with ctx.Pool(2) as pool:
+        both = pool.map(_render_lanes_crc, [(2, 48), (2, 48)], chunksize=1)
+    assert both == [solo, solo]
+
+
 def test_shared_gpu_and_oversubscribed_grid():
     """k_shade's ordered scan must not depend on its whole grid being resident: two processes rendering on the same GPU at the same
     time, and a grid of four times what the CUs hold (RT355_SHADE_PER_CU=16), finish without a device fault and reproduce the
@@ -754,3 +791,46 @@ def test_textured_plane_and_stray_texture_indices():
     assert np.array_equal(d.get_seeds(), seeds)
     assert acc[..., :3].sum() > 0
     d.close()
+
+
+def test_lanes_interleaved_sample_streams_match_oracle():
+    """dist.Lanes: two contexts on one GPU render disjoint sample streams of the same frame with their launches interleaved (bench.py's
+    default).  Each lane equals the oracle run on its seed slice, the rank's image is the sum of the lanes in lane order - bit for
+    bit - and it differs from the single-stream image only in which random numbers were drawn."""
+    from magr_ray_tracer_amd import dist as rdist
+    Wd, Hd, frames, lanes = 160, 90, 5, 2
+    s, view = scenes.sponza_class(0.2)
+    sa = s.arrays()
+    cam = scenes.camera_for(view, Wd, Hd)
+
+    def make(m):
+        d = Device(Wd, Hd, **DEFAULT)
+        d.upload(sa)
+        return d
+
+    def seeds_for(m):
+        p = rdist.plan("samples", Wd, Hd, 0, 1, m, lanes)
+        return seed_stream(p["seed_first"], p["seed_count"])
+
+    g = rdist.Lanes(lanes, make, seeds_for)
+    g.render(cam, frames)
+    g.synchronize()
+    total = g.read_accum()
+    parts = rdist.lane_frames(frames, lanes)
+    assert parts == [3, 2]
+    o = Oracle(sa, Wd, Hd, **DEFAULT)
+    ref = None
+    for m in range(lanes):
+        acc, seeds, e, c = o.render(cam, parts[m], seeds=seeds_for(m))
+        assert_bits(g.devs[m].read_accum(), acc, f"lane {m}")
+        assert np.array_equal(g.devs[m].get_seeds(), seeds)
+        ref = acc if ref is None else ref + acc
+    assert_bits(total, ref, "sum of lanes")
+    one = Device(Wd, Hd, **DEFAULT)
+    one.upload(sa)
+    one.seed_default()
+    one.render(cam, frames)
+    single = one.read_accum()
+    assert not bits_equal(single, total) and abs(float(single[..., :3].sum()) / float(total[..., :3].sum()) - 1) < 0.05
+    one.close()
+    g.close()
