@@ -3,7 +3,7 @@
 // the host code is the reference's call sequence (src/renderer.cpp:6-63, template main loop), the device work goes through
 // librt355.so.  There is no CPU path: without a HIP device Init() throws.
 //
-//   headless_tick [--obj model.obj] [--tex image.png] [--size W H] [--spp N] [--bvh4] [--kajiya] [--decorrelate] [--out frame.png]
+//   headless_tick [--obj model.obj] [--tex image.png] [--size W H] [--spp N] [--bvh4] [--kajiya] [--decorrelate] [--lanes N] [--out frame.png]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -12,7 +12,10 @@
 #include <string>
 #include <stdexcept>
 #include <vector>
+#include <algorithm>
+#include <memory>
 #include "../include/rt355.h"
+#include "../include/rt355_host.h"
 #include "../magr_ray_tracer_amd/host/rt_host.h"
 
 using namespace rt355;
@@ -44,6 +47,7 @@ int main(int argc, char** argv)
     int W = 1280, H = 720, spp = 64;
     std::string obj, tex, out = "frame.png";
     bool bvh4 = false, kajiya = false, decorrelate = false;
+    int lanes = 1;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "--obj" && i + 1 < argc) obj = argv[++i];
@@ -54,51 +58,71 @@ int main(int argc, char** argv)
         else if (a == "--bvh4") bvh4 = true;
         else if (a == "--kajiya") kajiya = true;
         else if (a == "--decorrelate") decorrelate = true;
+        else if (a == "--lanes" && i + 1 < argc) lanes = std::max(1, atoi(argv[++i]));
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     try {
-        Renderer r(W, H);
-        Scene& s = r.scene;
-        // materials the way the reference's Scene constructor sets them up (scene.cpp:14-43)
-        { RtMaterial& m = s.AddMaterial("white"); m.color = RtFloat4{ 0.9f, 0.9f, 0.9f, 0 }; }
-        { RtMaterial& m = s.AddMaterial("red"); m.color = RtFloat4{ 0.9f, 0.15f, 0.1f, 0 }; }
-        { RtMaterial& m = s.AddMaterial("green"); m.color = RtFloat4{ 0.15f, 0.8f, 0.2f, 0 }; }
-        { RtMaterial& m = s.AddMaterial("mirror"); m.color = RtFloat4{ 0.9f, 0.9f, 0.9f, 0 }; m.specular = 0.5f; }
-        { RtMaterial& m = s.AddMaterial("light"); m.color = RtFloat4{ 1, 1, 1, 0 }; m.isLight = 1; m.emittance = RtFloat4{ 40, 40, 40, 0 }; }
-        std::string floorMat = "white";
-        if (!tex.empty()) { s.LoadTexture(tex, "floor-texture"); floorMat = "floor-texture"; }
-        cornell_like(s, floorMat);
-        if (!obj.empty()) printf("loaded %d triangles from %s\n", s.LoadModel(obj, "white", float3(0, 0, 0), false), obj.c_str());
-        const auto t0 = std::chrono::steady_clock::now();
-        s.bvh2->BuildBLAS(true, 0);
-        const double buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        r.imgui.bvh = bvh4 ? 1 : 0;
-        r.imgui.shading = kajiya ? 0 : 1;
-        r.camera.cam.origin = RtFloat4{ 0, 5, 14, 0 };
-        r.camera.cam.forward = RtFloat4{ 0, 0, 1, 0 };     // the camera looks along -forward
-        r.camera.cam.aperture = 0.0f;
-        r.camera.Fov(60);
-        r.Init();
-        if (decorrelate) {
-            // The reference seeds pixel i with the (i+1)-th output of ONE xorshift32 stream and then advances every pixel with the same
-            // xorshift32 (template.cpp:724-730, util.cl:50-56): neighbouring pixels draw the same numbers one step apart, which shows
-            // as horizontal streaks at low sample counts.  That is what parity reproduces by default; a caller who does not need
-            // parity hands over independent seeds (here the reference's own, unused, initSeed = WangHash((i + 1) * 17), util.cl:37-48) through rt_set_seeds.
+        // One Renderer per lane.  Lane 0 alone is the reference's main loop; further lanes are independent sample streams of the same
+        // frame on the same GPU (own context and stream, the next slice of the host seed stream), ticked alternately so that the tails
+        // of one lane's launches are filled by the other's kernels (bench.py --lanes).
+        std::vector<std::unique_ptr<Renderer>> lane;
+        double buildMs = 0;
+        for (int m = 0; m < lanes; m++) {
+            lane.emplace_back(new Renderer(W, H));
+            Renderer& r = *lane.back();
+            Scene& s = r.scene;
+            // materials the way the reference's Scene constructor sets them up (scene.cpp:14-43)
+            { RtMaterial& mt = s.AddMaterial("white"); mt.color = RtFloat4{ 0.9f, 0.9f, 0.9f, 0 }; }
+            { RtMaterial& mt = s.AddMaterial("red"); mt.color = RtFloat4{ 0.9f, 0.15f, 0.1f, 0 }; }
+            { RtMaterial& mt = s.AddMaterial("green"); mt.color = RtFloat4{ 0.15f, 0.8f, 0.2f, 0 }; }
+            { RtMaterial& mt = s.AddMaterial("mirror"); mt.color = RtFloat4{ 0.9f, 0.9f, 0.9f, 0 }; mt.specular = 0.5f; }
+            { RtMaterial& mt = s.AddMaterial("light"); mt.color = RtFloat4{ 1, 1, 1, 0 }; mt.isLight = 1; mt.emittance = RtFloat4{ 40, 40, 40, 0 }; }
+            std::string floorMat = "white";
+            if (!tex.empty()) { s.LoadTexture(tex, "floor-texture"); floorMat = "floor-texture"; }
+            cornell_like(s, floorMat);
+            if (!obj.empty()) { const int n = s.LoadModel(obj, "white", float3(0, 0, 0), false); if (m == 0) printf("loaded %d triangles from %s\n", n, obj.c_str()); }
+            const auto t0 = std::chrono::steady_clock::now();
+            s.bvh2->BuildBLAS(true, 0);
+            if (m == 0) buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            r.imgui.bvh = bvh4 ? 1 : 0;
+            r.imgui.shading = kajiya ? 0 : 1;
+            r.camera.cam.origin = RtFloat4{ 0, 5, 14, 0 };
+            r.camera.cam.forward = RtFloat4{ 0, 0, 1, 0 };     // the camera looks along -forward
+            r.camera.cam.aperture = 0.0f;
+            r.camera.Fov(60);
+            r.Init();
             std::vector<uint32_t> seeds((size_t)W * H);
-            for (size_t i = 0; i < seeds.size(); i++) {
-                uint32_t v = ((uint32_t)i + 1u) * 17u;
-                v = (v ^ 61u) ^ (v >> 16); v *= 9u; v = v ^ (v >> 4); v *= 0x27d4eb2du; v = v ^ (v >> 15);
-                seeds[i] = v ? v : 1u;
+            if (decorrelate) {
+                // The reference seeds pixel i with the (i+1)-th output of ONE xorshift32 stream and then advances every pixel with the same
+                // xorshift32 (template.cpp:724-730, util.cl:50-56): neighbouring pixels draw the same numbers one step apart, which shows
+                // as horizontal streaks at low sample counts.  That is what parity reproduces by default; a caller who does not need
+                // parity hands over independent seeds (here the reference's own, unused, initSeed = WangHash((i + 1) * 17), util.cl:37-48).
+                for (size_t i = 0; i < seeds.size(); i++) {
+                    uint32_t v = ((uint32_t)(i + (size_t)m * seeds.size()) + 1u) * 17u;
+                    v = (v ^ 61u) ^ (v >> 16); v *= 9u; v = v ^ (v >> 4); v *= 0x27d4eb2du; v = v ^ (v >> 15);
+                    seeds[i] = v ? v : 1u;
+                }
+                if (rt_set_seeds(r.ctx, seeds.data(), (int64_t)seeds.size())) throw std::runtime_error(rt_last_error());
+            } else if (m > 0) {   // lane m continues the reference's host seed stream where lane m-1 stopped (virtual rank m)
+                if (rth_seed_stream(seeds.data(), (int64_t)m * W * H, (int64_t)seeds.size()) || rt_set_seeds(r.ctx, seeds.data(), (int64_t)seeds.size()))
+                    throw std::runtime_error("seeding lane failed");
             }
-            if (rt_set_seeds(r.ctx, seeds.data(), (int64_t)seeds.size())) throw std::runtime_error(rt_last_error());
         }
         const auto t1 = std::chrono::steady_clock::now();
-        for (int i = 0; i < spp; i++) r.Tick(0.016f);
-        r.ComputeEnergy();
+        for (int i = 0; i < spp; i++) lane[(size_t)(i % lanes)]->Tick(0.016f);     // Tick() only enqueues: the lanes overlap on the GPU
+        Renderer& r = *lane[0];
+        std::vector<RtFloat4> sum((size_t)W * H), part((size_t)W * H);
+        r.ReadAccum(sum.data());                                                  // (synchronises lane 0)
+        for (int m = 1; m < lanes; m++) {                                         // the image is the sum of the lanes, in lane order
+            lane[(size_t)m]->ReadAccum(part.data());
+            for (size_t i = 0; i < sum.size(); i++) { sum[i].x += part[i].x; sum[i].y += part[i].y; sum[i].z += part[i].z; sum[i].w += part[i].w; }
+        }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+        if (lanes > 1) { if (rt_write_accum(r.ctx, sum.data())) throw std::runtime_error(rt_last_error()); r.settings->frames = spp + 1; }
+        r.ComputeEnergy();
         r.SaveFrame(out.c_str());
-        printf("headless_tick: %zu primitives, BVH build %.1f ms, %d spp at %dx%d in %.1f ms (%.1f M samples/s), energy %.6g, wrote %s\n",
-               s.primitives.size(), buildMs, spp, W, H, ms, (double)W * H * spp / ms / 1e3, (double)r.energy_total, out.c_str());
+        printf("headless_tick: %zu primitives, BVH build %.1f ms, %d spp at %dx%d in %.1f ms (%.1f M samples/s, %d lane%s), energy %.6g, wrote %s\n",
+               r.scene.primitives.size(), buildMs, spp, W, H, ms, (double)W * H * spp / ms / 1e3, lanes, lanes > 1 ? "s" : "", (double)r.energy_total, out.c_str());
     } catch (const std::exception& e) {
         fprintf(stderr, "headless_tick: %s\n", e.what());
         return 1;

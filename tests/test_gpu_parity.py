@@ -697,6 +697,10 @@ def test_cpp_headless_tick_example(tmp_path):
     assert e1 == e2 and p1 == p2 and e1 > 0
     e4, _ = run(tmp_path / "c.png", "--bvh4")
     assert abs(e4 - e1) <= 1e-3 * e1
+    # two lanes (two Renderers on one GPU, ticked alternately, accumulators summed): deterministic, same image up to Monte-Carlo noise
+    l1, q1 = run(tmp_path / "d.png", "--lanes", "2")
+    l2, q2 = run(tmp_path / "e.png", "--lanes", "2")
+    assert l1 == l2 and q1 == q2 and abs(l1 - e1) <= 0.03 * e1
     # the PNG decodes to a 320x180 RGB frame that is not black
     assert p1[:8] == b"\x89PNG\r\n\x1a\n" and int.from_bytes(p1[16:20], "big") == 320 and int.from_bytes(p1[20:24], "big") == 180
     idat = b"".join(p1[i + 8:i + 8 + int.from_bytes(p1[i:i + 4], "big")] for i in _png_chunks(p1) if p1[i + 4:i + 8] == b"IDAT")
