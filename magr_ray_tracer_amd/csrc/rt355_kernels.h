@@ -855,6 +855,11 @@ RT_FORCEINLINE float4 prim_normal(const RtPrimitive* p, float4 I) // primitives.
 // Texel `i` of the atlas.  The reference indexes `textures` unchecked (primitives.cl:124,134,145): uv == 1 lands one texel or one row
 // past a texture and a plane with negative u or v up to a whole texture past it - inside the atlas that reads a neighbouring
 // texture's texel (reproduced), past its end it is undefined behaviour.  Here, and in the oracle, texels outside the atlas are zero.
+// float -> int with the hardware's own rule (v_cvt_i32_f32 / v_cvt_u32_f32: NaN -> 0, out of range saturates), spelled out so that it
+// is defined C++ rather than a poison fptosi.  It matters: a sphere hit found with w-lane-polluted dots has a non-unit normal,
+// acos(N.y) is then NaN and the reference's kernels read texel row 0 (tests/test_gpu_reference.py, whole-frame comparison).
+RT_FORCEINLINE int f2i_gpu(float x) { return x != x ? 0 : (x >= 2147483648.0f ? 2147483647 : (x <= -2147483648.0f ? (int)(-2147483647 - 1) : (int)x)); }
+RT_FORCEINLINE uint32_t f2u_gpu(float x) { return !(x > 0.0f) ? 0u : (x >= 4294967296.0f ? 0xffffffffu : (uint32_t)x); }
 RT_FORCEINLINE float4 texel(const DevScene& sc, long long i) { return i >= 0 && i < (long long)sc.nTex ? sc.tex[i] : splat(0.0f); }
 RT_FORCEINLINE float4 albedo_of(const DevScene& sc, const RtPrimitive* prim, const RtMaterial* mat, const SRay& ray) // primitives.cl:107-148
 {
@@ -869,18 +874,18 @@ RT_FORCEINLINE float4 albedo_of(const DevScene& sc, const RtPrimitive* prim, con
             float uy = fmodf(ray.u * t->uv1.y + ray.v * t->uv0.y + w2 * t->uv2.y, 1.f);
             if (ux < 0) ux = 1 + ux;
             if (uy < 0) uy = 1 + uy;
-            int x = (int)(ux * (float)texW), y = (int)(uy * (float)texH);
+            int x = f2i_gpu(ux * (float)texW), y = f2i_gpu(uy * (float)texH);
             albedo = texel(sc, (long long)texIdx + x + (long long)y * texW);
         } else if (type == RT_PRIM_SPHERE) {
             float ux = (float)((1 + atan2f(ray.N.z, ray.N.x) / 3.14159265358979323846) * 0.5);
             float uy = acosf(ray.N.y) / 3.14159265358979323846f;
-            int x = (int)(ux * (float)texW), y = (int)(uy * (float)texH);
+            int x = f2i_gpu(ux * (float)texW), y = f2i_gpu(uy * (float)texH);
             albedo = texel(sc, (long long)texIdx + x + (long long)y * texW);
         } else {
             float u = fmodf(ray.u, 1.f), v = fmodf(ray.v, 1.f);
             if (u < 0) u = 1 - u;
             if (v < 0) v = 1 - v;
-            int x = (int)(u * (float)texW), y = (int)(v * (float)texH);
+            int x = f2i_gpu(u * (float)texW), y = f2i_gpu(v * (float)texH);
             albedo = texel(sc, (long long)texIdx + x + (long long)y * texW);
         }
     }
@@ -983,7 +988,7 @@ RT_FORCEINLINE float4 shade_hit(const DevScene& sc, const DevVariant& var, SRay&
         const float4 albedo = albedo_of(sc, prim, mat, ray);
         const float4 BRDF = muls(albedo, kInvPi);
         if (NEE && sc.nLights > 0) {
-            uint32_t li = (uint32_t)floorf(rnd_abs(seed) * (float)sc.nLights);
+            uint32_t li = f2u_gpu(floorf(rnd_abs(seed) * (float)sc.nLights));
             if (li >= (uint32_t)sc.nLights) li = (uint32_t)sc.nLights - 1; // reference reads out of bounds here (draw == 1.0)
             const uint32_t lightIdx = sc.lights[li];
             const RtPrimitive* lp = sc.prims + lightIdx;

@@ -184,6 +184,49 @@ def mixed_scene(alpha=1.0, textured=True):
     return s, view
 
 
+def branch_scene(alpha=1.0):
+    """A row of objects at eye level in a textured room, so that ONE thin horizontal band of the frame drives every shading
+    branch of the reference within a few bounces: textured triangles (floor, back wall), a textured sphere (lat-long lookup),
+    a thick absorbing glass box (inside rays, Beer's law, total internal reflection at its side faces), a glass sphere, a
+    mirror sphere, a sphere light and an upright triangle light seen directly (emissive hit with lastSpecular set), both of
+    them and a ceiling quad light sampled by NEE (emissive hit after a diffuse bounce returns black)."""
+    s = Scene()
+    _std_materials(s)
+    s.AddMaterial("thick-glass", material(color=(1, 1, 1), dielectric=True, n1=1.0, n2=1.5, specular=0.04, absorption=(0.9, 0.25, 0.1)))
+    yy, xx = np.mgrid[0:16, 0:16]
+    tex = np.zeros((16, 16, 4), dtype=np.float32)
+    tex[..., 0] = 0.25 + 0.6 * ((xx // 2 + yy // 2) % 2)
+    tex[..., 1] = 0.3 + 0.04 * xx
+    tex[..., 2] = 0.85 - 0.04 * yy
+    s.AddTexture("checker", tex)
+    yy, xx = np.mgrid[0:8, 0:32]
+    tex2 = np.zeros((8, 32, 4), dtype=np.float32)
+    tex2[..., 0] = 0.15 + 0.025 * xx
+    tex2[..., 1] = 0.75 - 0.07 * yy
+    tex2[..., 2] = 0.3 + 0.5 * (xx % 2)
+    s.AddTexture("stripes", tex2)
+    # textured floor and back wall (uv beyond 1: the fmod wrap), plain side walls and ceiling
+    s.AddTriangle((-6, 0, -5), (-6, 0, 6), (6, 0, 6), "checker", uv0=(0, 0), uv1=(0, 4), uv2=(4, 4))
+    s.AddTriangle((6, 0, 6), (6, 0, -5), (-6, 0, -5), "checker", uv0=(4, 4), uv1=(4, 0), uv2=(0, 0))
+    s.AddTriangle((-6, 0, -5), (6, 0, -5), (6, 4, -5), "stripes", uv0=(0, 0), uv1=(2.5, 0), uv2=(2.5, 1.5))
+    s.AddTriangle((6, 4, -5), (-6, 4, -5), (-6, 0, -5), "stripes", uv0=(2.5, 1.5), uv1=(0, 1.5), uv2=(0, 0))
+    s.AddQuad((-6, 0, -5), (-6, 4, -5), (-6, 4, 6), (-6, 0, 6), "red")
+    s.AddQuad((6, 0, -5), (6, 0, 6), (6, 4, 6), (6, 4, -5), "green")
+    s.AddQuad((-6, 4, -5), (6, 4, -5), (6, 4, 6), (-6, 4, 6), "white")
+    # the row of objects, centres at y = 1
+    s.AddTriangles(box_tris((-4.6, 0.3, -0.7), (-3.2, 1.7, 0.7)), "thick-glass")
+    s.AddSphere((-2.2, 1.0, 0.0), 0.7, "checker")
+    s.AddSphere((-0.6, 1.0, 0.2), 0.7, "mirror")
+    s.AddSphere((0.7, 1.0, -0.3), 0.35, "green-light")
+    s.AddTriangle((1.4, 0.5, -1.0), (2.4, 0.5, -1.0), (1.9, 1.6, -1.0), "red-light")          # upright, faces +z (the camera)
+    s.AddSphere((3.0, 1.0, 0.1), 0.65, "white-glass")
+    s.AddSphere((4.5, 1.0, 0.0), 0.7, "sand")
+    s.AddQuad((-1.2, 3.95, -1.2), (1.2, 3.95, -1.2), (1.2, 3.95, 1.2), (-1.2, 3.95, 1.2), "white-light")   # faces down
+    s.BuildBLAS(0, alpha)
+    view = dict(origin=(0.0, 1.0, 5.6), forward=(0.0, 0.0, 1.0), fov=80.0, aperture=0.03)
+    return s, view
+
+
 def two_blas_scene(alpha=0.0, n=24):
     """Two BLAS under a TLAS (shape of config 5): a displaced blob and a torus-like ring, each its own
     BuildBLAS call, SBVH alpha given; a glass sphere sits in the second BLAS."""
@@ -246,4 +289,4 @@ def config5_scene(alpha=0.0, decimate=1):
 
 def camera_for(view, width, height, focalLength=1.0):
     return make_camera(width, height, view["origin"], view["forward"], fov=view.get("fov", 110.0),
-                       aperture=view.get("aperture", 0.1), focalLength=focalLength)
+                       aperture=view.get("aperture", 0.1), focalLength=focalLength, type=view.get("type", 0))

@@ -227,6 +227,23 @@ static f4 prim_normal(const RtPrimitive* p, f4 I) /* primitives.cl:91-105 */
     }
 }
 static inline float fmod1(float x) { return fmodf(x, 1.f); }
+/* float -> int as the GPU converts (v_cvt_i32_f32 / v_cvt_u32_f32: NaN -> 0, out of range saturates).  OpenCL C leaves both
+ * cases undefined and x86 returns INT_MIN for them; they DO occur on the path: a sphere hit found with w-lane-polluted dots
+ *  has a non-unit normal, acospi(N.y) of |N.y| > 1 is NaN, and the reference's kernels (and the HIP path)
+ * then read texel row 0.  Found by the whole-frame comparison with the reference's kernels (tests/test_gpu_reference.py). */
+static inline int f2i_gpu(float x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return (int)(-2147483647 - 1);
+    return (int)x;
+}
+static inline uint32_t f2u_gpu(float x)
+{
+    if (!(x > 0.0f)) return 0u;                 /* NaN and negatives */
+    if (x >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)x;
+}
 /* The reference indexes `textures` unchecked (primitives.cl:124,134,145); texels outside the atlas are zero here and in the HIP path
  * (inside the atlas a stray index reads the neighbouring texture's texel, as the reference does). */
 static inline f4 texel(const OrcScene* sc, long long i) { f4 z = { 0, 0, 0, 0 }; return i >= 0 && i < (long long)sc->nTex ? sc->tex[i] : z; }
@@ -244,20 +261,20 @@ static f4 albedo_of(const RtRay* ray, const OrcScene* sc) /* primitives.cl:107-1
             float uy = fmod1(ray->u * t->uv1.y + ray->v * t->uv0.y + w2 * t->uv2.y);
             if (ux < 0) ux = 1 + ux;
             if (uy < 0) uy = 1 + uy;
-            int x = (int)(ux * (float)mat->texW), y = (int)(uy * (float)mat->texH);
+            int x = f2i_gpu(ux * (float)mat->texW), y = f2i_gpu(uy * (float)mat->texH);
             albedo = texel(sc, (long long)mat->texIdx + x + (long long)y * mat->texW);
         } break;
         case RT_PRIM_SPHERE: {
             float ux = (float)((1 + atan2f(ray->N.z, ray->N.x) / 3.14159265358979323846) * 0.5); /* atan2pi, double 0.5 */
             float uy = acosf(ray->N.y) / 3.14159265358979323846f;
-            int x = (int)(ux * (float)mat->texW), y = (int)(uy * (float)mat->texH);
+            int x = f2i_gpu(ux * (float)mat->texW), y = f2i_gpu(uy * (float)mat->texH);
             albedo = texel(sc, (long long)mat->texIdx + x + (long long)y * mat->texW);
         } break;
         case RT_PRIM_PLANE: {
             float u = fmod1(ray->u), v = fmod1(ray->v);
             if (u < 0) u = 1 - u;
             if (v < 0) v = 1 - v;
-            int x = (int)(u * (float)mat->texW), y = (int)(v * (float)mat->texH);
+            int x = f2i_gpu(u * (float)mat->texW), y = f2i_gpu(v * (float)mat->texH);
             albedo = texel(sc, (long long)mat->texIdx + x + (long long)y * mat->texW);
         } break;
         }
@@ -503,7 +520,7 @@ static f4 shade_nee(RtRay* ray, RtRay* ext, RtShadowRay* shadow, uint32_t* seed,
         if (sc->nLights > 0) {
             /* reference reads lights[numLights] when the draw is exactly 1.0 (out of bounds,
              * probability 2^-25 per draw); both this oracle and the HIP path clamp instead. */
-            uint32_t li = (uint32_t)floorf(rnd_abs(seed) * (float)sc->nLights);
+            uint32_t li = f2u_gpu(floorf(rnd_abs(seed) * (float)sc->nLights));
             if (li >= (uint32_t)sc->nLights) li = (uint32_t)sc->nLights - 1;
             uint32_t lightIdx = sc->lights[li];
             const RtPrimitive* lp = &sc->prims[lightIdx];

@@ -113,13 +113,19 @@ class RefGPU:
         self.launch("generate", n, 256, [d_rays, self.d_set, d_seeds, np.ascontiguousarray(cam).reshape(1)])
         return self.rd(d_rays, W.Ray, n), self.rd(d_seeds, np.uint32, n)
 
-    def extend(self, rays):
-        """One work-group of 256 work-items (the kernel's counter swap sits behind a work-group barrier)."""
+    def extend(self, rays, renderBVH=False):
+        """One work-group of 256 work-items (the kernel's counter swap sits behind a work-group barrier).
+        renderBVH: also returns the reference's own heat-map values accum[slot] = steps / 255 (wavefront.cl:66-67)."""
         n = len(rays)
         d_rays = self.dbuf(rays)
+        self.settings["renderBVH"] = int(renderBVH)
         self.set_counts(0, n, 0)
         self.launch("extend", 256, 256, [d_rays, self.prims, self.tlas, self.blas, self.nodes, self.idx, self.accum, self.d_set])
-        return self.rd(d_rays, W.Ray, n)
+        self.settings["renderBVH"] = 0
+        out = self.rd(d_rays, W.Ray, n)
+        if renderBVH:
+            return out, self.rd(self.accum, np.float32, 4 * n).reshape(n, 4)
+        return out
 
     def shade_s0(self, rays, seeds):
         """Global size 1: schedule S0 (descending slots, stream seeds[0])."""
@@ -135,6 +141,55 @@ class RefGPU:
         d_sh = self.dbuf(shadow)
         self.set_counts(0, 0, len(shadow))
         self.launch("connect", 1, 1, [d_sh, self.tlas, self.blas, self.nodes, self.idx, self.prims, self.mats, self.d_set, self.accum])
+
+    def frame_s0(self, cam, y0, y1, shading=1, russian_roulette=True, seeds_first=None, bounces=7):
+        """One whole Renderer::RayTrace() (reference src/renderer.cpp:64-94) over the rows [y0, y1) of the reference's
+        compile-time 1280x720 frame, driven through the reference's own kernels in the reference's order:
+            settings{numInRays 0, numOutRays n, shadowRays 0};  generate;
+            7 x { extend (one work-group of 256), shade (ONE work-item = schedule S0), [connect if !RR and NEE], swap };
+            [connect if RR].
+        generate derives the pixel from get_global_id (wavefront.cl:26-33), so it is launched over rows [0, y1) and the band's
+        rays / seeds are the tail of what it wrote; shade's RNG stream is the band's seeds[0] (wavefront.cl:97 with one
+        work-item).  Returns the per-bounce captures (rays after extend, queue lengths, RNG state) and the accumulator."""
+        first, n, n_all = y0 * REF_W, (y1 - y0) * REF_W, y1 * REF_W
+        assert n_all % 256 == 0
+        from oracle.oracle_py import seed_stream
+        seeds_all = seed_stream(0, n_all)
+        d_all, d_seeds_all = self.dbuf(nbytes=128 * n_all), self.dbuf(seeds_all)
+        self.set_counts(0, n, 0)                                      # renderer.cpp:66-69
+        self.launch("generate", n_all, 256, [d_all, self.d_set, d_seeds_all, np.ascontiguousarray(cam).reshape(1)])
+        gen = self.rd(d_all, W.Ray, n_all)[first:].copy()
+        seeds = self.rd(d_seeds_all, np.uint32, n_all)[first:].copy()
+        ray1, ray2 = self.dbuf(gen), self.dbuf(nbytes=128 * n)
+        d_sh, d_seeds = self.dbuf(nbytes=96 * n * bounces), self.dbuf(seeds)
+        self.clear_accum()
+        cap = dict(gen=gen, gen_seeds=seeds.copy(), ext=[], n_in=[], n_out=[], n_shadow=[], seed0=[], shadow=None)
+        nee = shading == 1
+        n_in = n
+        for b in range(bounces):                                      # renderer.cpp:75-90
+            self.launch("extend", 256, 256, [ray1, self.prims, self.tlas, self.blas, self.nodes, self.idx, self.accum, self.d_set])
+            cap["n_in"].append(n_in)
+            cap["ext"].append(self.rd(ray1, W.Ray, n)[:n_in].copy())
+            self.launch("shade", 1, 1, [ray1, ray2, d_sh, self.prims, self.tex, self.mats, self.lights, self.d_set, self.accum, d_seeds])
+            st = self.get_settings()
+            n_in = int(st["numOutRays"])
+            cap["n_out"].append(n_in)
+            cap["n_shadow"].append(int(st["shadowRays"]))
+            cap["seed0"].append(int(self.rd(d_seeds, np.uint32, 1)[0]))
+            if not russian_roulette and nee:                          # renderer.cpp:85-87
+                if cap["shadow"] is None:
+                    cap["shadow"] = []
+                cap["shadow"].append(self.rd(d_sh, W.ShadowRay, max(int(st["shadowRays"]), 1))[:int(st["shadowRays"])].copy())
+                self.launch("connect", 1, 1, [d_sh, self.tlas, self.blas, self.nodes, self.idx, self.prims, self.mats, self.d_set, self.accum])
+            ray1, ray2 = ray2, ray1
+        cap["last_out"] = self.rd(ray1, W.Ray, n)[:n_in].copy()       # appended by the 7th shade, never traced
+        if russian_roulette:                                          # renderer.cpp:91-92
+            ns = int(self.get_settings()["shadowRays"])
+            cap["shadow"] = [self.rd(d_sh, W.ShadowRay, max(ns, 1))[:ns].copy()]
+            self.launch("connect", 1, 1, [d_sh, self.tlas, self.blas, self.nodes, self.idx, self.prims, self.mats, self.d_set, self.accum])
+        cap["accum"] = self.rd(self.accum, np.float32, 4 * REF_W * y1).reshape(y1 * REF_W, 4)[first:].copy()
+        cap["first_pixel"] = first
+        return cap
 
     def focus(self, x, y, cam):
         self.launch("focus", 1, 1, [np.array([x], np.int32), np.array([y], np.int32), self.tlas, self.blas, self.nodes, self.idx,

@@ -364,3 +364,37 @@ def test_parallel_build_is_index_exact(alpha):
     assert a1.bvh2.tobytes() == a4.bvh2.tobytes() and np.array_equal(a1.primIdx, a4.primIdx)
     for k in ("nodes", "depth", "spatial_splits", "prims_clipped"):
         assert st1[k] == st4[k], k
+
+
+# ---- whole frames of the reference's own kernels (renderer.cpp:64-94 launch sequence, schedule S0), captured on the MI355X -------
+FRAMES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "refframe_*.npz")))
+
+
+@pytest.mark.parametrize("path", FRAMES, ids=[os.path.basename(p) for p in FRAMES])
+def test_oracle_follows_reference_frames_launch_by_launch(path):
+    """Every launch of a whole reference frame (7 x extend/shade, connect per bounce or deferred) replayed through the oracle from
+    the reference's rays and RNG state: see helpers.teacher_forced_s0.  The fixtures hold a band that drives every shading
+    branch; the branch counts recomputed from the oracle's rays must equal the ones recorded from the reference's."""
+    from helpers import branch_counts, load_frame_fixture, teacher_forced_s0
+    sa, v, cam, (Wd, Hd, y0, y1), cap, heat, bc = load_frame_fixture(path)
+    o = Oracle(sa, Wd, Hd, **v, schedule=S0)
+    mine = []
+    stats = teacher_forced_s0(o, cap, sa, os.path.basename(path), full_rays=False, collect=mine)
+    got = branch_counts(dict(ext=mine, shadow=cap["shadow"], last_out=cap["last_out"]), sa)
+    assert got == bc, (got, bc)
+    if "branch" in os.path.basename(path) and "_free_" not in os.path.basename(path):
+        need = ["light_spec", "tex_tri", "tex_sphere", "inside", "inside_dielectric", "tir", "last_bounce"]
+        if v["shading"] == 1:     # Kajiya has no shadow rays and never sets lastSpecular on a child ray (shading.cl:7-70)
+            need += ["light_spec_later", "light_nospec", "sphere_light_shadow", "tri_light_shadow"]
+        assert all(bc[k] > 0 for k in need), bc
+    if "_free_" in os.path.basename(path):
+        # a band on which no knife-edge decision flips: the oracle, running freely from the seeds, stays on the reference's frame
+        from helpers import compare_frames_s0, oracle_frame_s0
+        print(compare_frames_s0(cap, oracle_frame_s0(o, cam, y0, y1), os.path.basename(path)))
+    # the reference's own heat-map values of the primary rays: accum[slot] = steps / 255.f (wavefront.cl:66-67)
+    n = (y1 - y0) * Wd
+    seeds = seed_stream(y0 * Wd, n)
+    rays = o.generate(cam, y0 * Wd, n, seeds)
+    steps, _ = o.extend(rays, want_steps=True)
+    assert_bits(steps.astype(np.float32) / np.float32(255.0), heat, "steps / 255 of the primary rays")
+    assert stats["rays"] > 3000
