@@ -9,19 +9,32 @@ Scene, BVH and seeds are resident in HBM before the timed region.  The samples a
 across the N ranks (one process per GPU, torch.distributed / RCCL, one all_reduce(SUM) of the accumulator inside the timed
 region) and, inside a GPU, across `--lanes` independent contexts whose frames are interleaved so that the tails of one context's
 launches are filled by the other's kernels; a rank's `steps` frames are shared out over its lanes.
+
+Launching: `python bench.py --gpus N` starts its own N ranks (fresh child processes, spawned before this process touches the
+GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks.
+
+Timed region: exactly `--steps` frames between barrier + synchronize brackets, MAX over ranks.  A region shorter than 0.25 s says
+little (20 steps are 57 ms), so the bracketed K-step region is repeated until 0.25 s of it have been timed; `value` and
+`ms_per_step` are over all repeats (`repeats` in the line).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+MIN_TIMED_S = 0.25      # repeat the K-step region until this much has been timed
+# tools/gather_probe.hip on the MI355X (profiles/r02_gather_probe.log): dependent random 64-byte record fetches + two slab tests,
+# no divergence.  By table size: <= 4 MB 200 G records/s (L1/L2 resident), 8 MB 168, 32 MB 118 (Infinity Cache).  The traversal's
+# 21 MB of records are fetched with 86 % vector-L1 and 82 % L2 hits (profiles/r01_pmc_final_summary.csv), i.e. its EFFECTIVE
+# working set is the small-table regime: the honest ceiling for the access pattern is the 200 G/s row.
+GATHER_CEILING_RECORDS_PER_S = 200e9
 
 
 def extend_bytes(c, accel, prefix="extend"):
@@ -31,7 +44,7 @@ def extend_bytes(c, accel, prefix="extend"):
             c[prefix + "_node_visits"] * node + c[prefix + "_prim_tests"] * 52)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256, help="frames (1 spp each) in the timed region; 256 = BASELINE config 3")
@@ -40,15 +53,58 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--detail", type=float, default=1.0, help="sponza-class tessellation (1.0 = ~262k triangles)")
     ap.add_argument("--accel", choices=["bvh2", "bvh4"], default="bvh2")
-    ap.add_argument("--shard", choices=["samples", "bands"], default="samples")
+    ap.add_argument("--shard", choices=["samples", "bands", "ibands"], default="samples")
     ap.add_argument("--lanes", type=int, default=2, help="independent sample streams per GPU whose frames overlap (samples plan only; 1 = one context)")
     ap.add_argument("--extend-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stage launches with HIP events")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (default); gloo only for rehearsals")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses GPU 0 (requires --backend gloo)")
-    args = ap.parse_args()
+    ap.add_argument("--no-repeat", action="store_true", help="time the K-step region once, however short it is")
+    ap.add_argument("--dump-accum", default=None, help="rank 0 writes the reduced accumulator (npy) here after the timed region")
+    return ap.parse_args()
 
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` from a bare shell: start N fresh rank processes (this process has not touched the GPU and does
+    not exec), pass their output through, wait for all of them; a failing rank ends the others and makes the exit code non-zero."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            time.sleep(0.2)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in live:        # the others would wait for it in a collective forever
+                        q.terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc if rc >= 0 else 1
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
+    if args.same_device and args.gpus > 1 and args.backend != "gloo":
+        raise SystemExit("--same-device puts every rank on GPU 0, which RCCL refuses: use --backend gloo")
+
+    import numpy as np
     import torch
     from magr_ray_tracer_amd import dist as rdist, scenes
     from magr_ray_tracer_amd.renderer import Device
@@ -72,25 +128,26 @@ def main():
     # fully-bracketed pass afterwards, outside the timed region
     cam = scenes.camera_for(view, W, H)
     accums = [torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}") for _ in range(lanes)]
+    reduced = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}")
 
-    def make_device(m):
-        p = rdist.plan(args.shard, W, H, rank, world, m, lanes)
-        d = Device(W, H, y0=p["y0"], y1=p["y1"], accel=accel, device=local, profile=0 if args.no_profile else 1,
-                   extend_variant=args.extend_variant)
-        d.upload(sa)
-        d.bind_accum(accums[m])
-        return d
+    def make_devices(m):
+        """One lane = one context; the interleaved-band plan gives a rank several row bands = several contexts."""
+        out = []
+        for p in rdist.plans(args.shard, W, H, rank, world, m, lanes):
+            d = Device(W, H, y0=p["y0"], y1=p["y1"], accel=accel, device=local, profile=0 if args.no_profile else 1,
+                       extend_variant=args.extend_variant)
+            d.upload(sa)
+            d.bind_accum(accums[m])
+            seeds = np.zeros(p["seed_count"], np.uint32)
+            _seed_stream(seeds, p["seed_first"])
+            d.set_seeds(seeds)
+            out.append(d)
+        return out
 
-    def seeds_for(m):
-        p = rdist.plan(args.shard, W, H, rank, world, m, lanes)
-        seeds = np.zeros(p["seed_count"], np.uint32)
-        _seed_stream(seeds, p["seed_first"])
-        return seeds
-
-    group = rdist.Lanes(lanes, make_device, seeds_for)
+    group = rdist.Lanes([d for m in range(lanes) for d in make_devices(m)])
     dev = group.devs[0]
+    each = args.shard != "samples"     # band plans: the contexts are parts of ONE frame, every one renders every step
     cam["focalLength"] = dev.focus(W // 2, H // 2, cam)
-    accum = accums[0]
 
     def barrier():
         torch.cuda.synchronize()
@@ -99,13 +156,22 @@ def main():
             torch.cuda.synchronize()
 
     def reduce_all():
+        reduced.copy_(accums[0])
         for a in accums[1:]:      # the rank's accumulator = sum of its lanes in lane order ...
-            accum.add_(a)
-        rdist.reduce_accumulator(accum)   # ... then the one exchange step across ranks
+            reduced.add_(a)
+        rdist.reduce_accumulator(reduced)   # ... then the one exchange step across ranks
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local}" if args.backend == "nccl" else "cpu")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
 
     # ---- warmup ------------------------------------------------------------------------------------------
     if args.warmup > 0:
-        group.render(cam, args.warmup * lanes)
+        group.render(cam, args.warmup * (1 if each else len(group)), each=each)
         group.synchronize()
         reduce_all()
     for d in group.devs:
@@ -117,18 +183,33 @@ def main():
         a.zero_()
     barrier()
 
-    # ---- timed region: exactly `steps` frames (shared out over the lanes) + the accumulator reduction -----------
-    t0 = time.perf_counter()
-    group.render(cam, args.steps)
-    group.synchronize()
-    reduce_all()
-    barrier()
-    dt = time.perf_counter() - t0
-    checksum = float(accum[..., :3].sum().item())
+    # ---- timed region: exactly `steps` frames (shared out over the lanes) + the accumulator reduction, repeated ---------------
+    dts, render_s, reduce_s = [], 0.0, 0.0
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        group.render(cam, args.steps, each=each)
+        group.synchronize()
+        t1 = time.perf_counter()
+        reduce_all()
+        t2 = time.perf_counter()
+        barrier()
+        dts.append(max_over_ranks(time.perf_counter() - t0))
+        render_s += t1 - t0
+        reduce_s += t2 - t1
+        if args.no_repeat or sum(dts) >= MIN_TIMED_S or len(dts) >= 256:
+            break
+    dt, repeats = sum(dts), len(dts)
+    frames_timed = args.steps * repeats
+    checksum = float(reduced[..., :3].sum().item())
+    if args.dump_accum and rank == 0:
+        np.save(args.dump_accum, reduced.cpu().numpy())
+    per_rank = [[render_s, reduce_s]]
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}" if args.backend == "nccl" else "cpu")
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine = torch.tensor([render_s, reduce_s], dtype=torch.float64, device=f"cuda:{local}" if args.backend == "nccl" else "cpu")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        per_rank = [[float(x[0]), float(x[1])] for x in allr]
 
     ctr, st = {}, {}
     for d in group.devs:          # totals over the lanes
@@ -136,65 +217,96 @@ def main():
             ctr[k] = ctr.get(k, 0) + v
         for k, v in d.stage_times().items():
             st[k] = st.get(k, 0) + v
-    stage_tab, con_ms, con_launches, con_bytes = {}, 0.0, 0, 0
-    single = {}
-    if not args.no_profile and rank == 0:   # untimed: 16 more frames of ONE context with every stage bracketed (kernels undisturbed)
-        dev.set_profile(2)
-        dev.reset_stage_times()
-        c0 = dev.counters()
-        dev.render(cam, 16)
+
+    # ---- untimed: ONE context with the GPU to itself (the reference's own shape: one Renderer) -----------------------------------
+    single, stage_tab, con = {}, {}, {}
+    value_single = None
+    if args.shard == "samples":
+        barrier()
+        n1 = max(16, min(args.steps, 64))
+        t0 = time.perf_counter()
+        dev.render(cam, n1)
         dev.synchronize()
-        st2, c1 = dev.stage_times(), dev.counters()
-        stage_tab = {k[:-3]: round(st2[k] / 16, 4) for k in st2 if k.endswith("_ms") and k != "compact_ms"}
-        con_ms, con_launches = st2["connect_ms"], st2["connect_launches"]
-        dctr = {k: c1[k] - c0[k] for k in c1}
-        con_bytes = extend_bytes(dctr, accel, "connect")
-        e_ms = st2["extend_ms"] / max(st2["extend_launches"], 1)
-        e_gbs = extend_bytes(dctr, accel) / max(st2["extend_launches"], 1) / (e_ms * 1e-3) / 1e9 if e_ms > 0 else 0.0
-        single = {"achieved": round(e_gbs, 2), "frac": round(e_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(e_ms, 5),
-                  "note": "the same kernel with the GPU to itself (one context, 16 untimed frames after the timed region)"}
-    samples = W * H * args.steps * (world if args.shard == "samples" else 1)
+        value_single = W * H * n1 / max_over_ranks(time.perf_counter() - t0) / 1e6 * world
+        if not args.no_profile and rank == 0:   # 16 more frames of that context with every stage bracketed (kernels undisturbed)
+            dev.set_profile(2)
+            dev.reset_stage_times()
+            c0 = dev.counters()
+            dev.render(cam, 16)
+            dev.synchronize()
+            st2, c1 = dev.stage_times(), dev.counters()
+            stage_tab = {k[:-3]: round(st2[k] / 16, 4) for k in st2 if k.endswith("_ms") and k != "compact_ms"}
+            dctr = {k: c1[k] - c0[k] for k in c1}
+            e_ms = st2["extend_ms"] / max(st2["extend_launches"], 1)
+            e_gbs = extend_bytes(dctr, accel) / max(st2["extend_launches"], 1) / (e_ms * 1e-3) / 1e9 if e_ms > 0 else 0.0
+            e_rec = (dctr["extend_node_visits"] + dctr["extend_prim_tests"]) / (st2["extend_ms"] * 1e-3) if st2["extend_ms"] > 0 else 0.0
+            single = {"achieved": round(e_gbs, 2), "frac": round(e_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(e_ms, 5),
+                      "gather_records_per_s": round(e_rec, 0), "gather_frac": round(e_rec / GATHER_CEILING_RECORDS_PER_S, 4),
+                      "note": "the same kernel with the GPU to itself (one context, 16 untimed frames after the timed region)"}
+            c_ms = st2["connect_ms"] / max(st2["connect_launches"], 1)
+            c_rec = (dctr["connect_node_visits"] + dctr["connect_prim_tests"]) / (st2["connect_ms"] * 1e-3) if st2["connect_ms"] > 0 else 0.0
+            c_gbs = extend_bytes(dctr, accel, "connect") / max(st2["connect_launches"], 1) / (c_ms * 1e-3) / 1e9 if c_ms > 0 else 0.0
+            con = {"achieved": round(c_gbs, 2), "frac": round(c_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(c_ms, 5),
+                   "gather_records_per_s": round(c_rec, 0), "gather_frac": round(c_rec / GATHER_CEILING_RECORDS_PER_S, 4),
+                   "rays_per_launch": dctr["connect_rays"] // max(st2["connect_launches"], 1),
+                   "note": "connect is an any-hit traversal with its own visit order; its counters are its own work, not the reference's"}
+        barrier()
+
+    nshare = world if args.shard == "samples" else 1
+    samples = W * H * frames_timed * nshare
     value = samples / dt / 1e6
 
     if rank == 0:
-        ext_ms = st["extend_ms"] / max(st["extend_launches"], 1)
-        ext_bytes = extend_bytes(ctr, accel) / max(st["extend_launches"], 1)
+        ext_launches = max(st["extend_launches"], 1)
+        ext_ms = st["extend_ms"] / ext_launches
+        ext_bytes = extend_bytes(ctr, accel) / ext_launches
         ext_gbs = ext_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-        con_ms = con_ms / max(con_launches, 1)
-        con_gbs = (con_bytes / max(con_launches, 1)) / (con_ms * 1e-3) / 1e9 if con_ms > 0 else 0.0
-        traffic = None
+        ext_rec = (ctr["extend_node_visits"] + ctr["extend_prim_tests"]) / (st["extend_ms"] * 1e-3) if st["extend_ms"] > 0 else 0.0
+        traffic, traffic_note = None, "no PMC measurement committed for this configuration"
         tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                same = tj.get("config", {}) == {"accel": args.accel, "detail": args.detail, "width": W, "height": H}
+                if same:
+                    traffic, traffic_note = tj.get("hbm_bytes_per_launch"), tj.get("source", "")
             except Exception:
-                traffic = None
+                pass
         traced = ctr["extend_rays"] + ctr["connect_rays"]
+        roof = {"bound": "hbm", "kernel": "extend = " + dev.extend_kernel_name(), "achieved": round(ext_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ext_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(ext_bytes), "avg_launch_ms": round(ext_ms, 5), "launches": st["extend_launches"],
+                "dram_frac": round(traffic / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and ext_ms > 0 else None,
+                "traffic_note": traffic_note,
+                "limiter": "memory latency + divergence of a dependent random-gather chain (vector L1 / L2 hits), not HBM bandwidth: `frac` is "
+                           "SURVEY 8(d)'s algorithmic bytes over the HBM peak and may exceed 1 because ~21 MB of node and triangle records "
+                           "are served from L1/L2/Infinity Cache; `dram_frac` is the measured DRAM-side traffic over the same peak; "
+                           "`gather` prices the kernel against what the chip sustains for its access pattern",
+                "gather": {"records_per_s": round(ext_rec, 0), "ceiling_records_per_s": GATHER_CEILING_RECORDS_PER_S,
+                           "frac": round(ext_rec / GATHER_CEILING_RECORDS_PER_S, 4),
+                           "note": "records = interior-node pair fetches + triangle-record fetches of all extend launches / their summed HIP-event "
+                                   "time; ceiling = tools/gather_probe.hip at the table size that matches the measured L1/L2 hit rates (<= 4 MB rows, "
+                                   "profiles/r02_gather_probe.log).  With lanes > 1 two contexts' launches overlap, so the per-launch rate is below "
+                                   "`single_stream` while the frame rate is higher"},
+                "single_stream": single,
+                "per_ray": {"node_visits": round(ctr["extend_node_visits"] / max(ctr["extend_rays"], 1), 2),
+                            "prim_tests": round(ctr["extend_prim_tests"] / max(ctr["extend_rays"], 1), 2)}}
         out = {
             "metric": "Mrays/sec + extend-kernel HBM GB/s, sponza 1080p 256spp",
             "value": round(value, 3), "unit": "Mrays/s (primary samples/s, reference definition renderer.cpp:60-62)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / frames_timed * 1e3, 4),
             "higher_is_better": True, "scaling": "weak" if args.shard == "samples" else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"sponza-class procedural atrium ({len(sa.prims)} prims, SAH {args.accel.upper()}, "
                                    f"{len(sa.bvh2)} nodes) {W}x{H}, NEE+cosine+RR+firefly, 7 bounces; step = 1 spp frame, "
                                    f"{args.steps} spp timed per GPU (BASELINE config 3 = 256 spp) as {lanes} interleaved sample stream(s)",
                        "shard": args.shard, "lanes": lanes, "triangles": int(len(sa.prims)), "extend_variant": args.extend_variant},
-            "traced_mrays_per_s": round(traced * (world if args.shard == "samples" else 1) / dt / 1e6, 2),
-            "rays_per_step": {"extend": ctr["extend_rays"] // args.steps, "connect": ctr["connect_rays"] // args.steps},
-            "roofline": {"bound": "hbm", "kernel": "extend (k_trace_persist<false>)", "achieved": round(ext_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ext_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(ext_bytes), "avg_launch_ms": round(ext_ms, 5),
-                         "launches": st["extend_launches"],
-                         "note": "achieved = algorithmic bytes (SURVEY 8(d) formula x device counters) / HIP-event time; node and triangle data "
-                                 "(~21 MB) are served from L1/L2/Infinity Cache, so achieved may exceed the HBM peak while `traffic` (PMC, DRAM side) stays "
-                                 "far below it.  With lanes > 1 the launches of different sample streams share the GPU, so a launch takes longer than it "
-                                 "does alone (`single_stream`) while the frame rate goes up",
-                         "single_stream": single,
-                         "per_ray": {"node_visits": round(ctr["extend_node_visits"] / max(ctr["extend_rays"], 1), 2),
-                                     "prim_tests": round(ctr["extend_prim_tests"] / max(ctr["extend_rays"], 1), 2)}},
-            "connect_roofline": {"achieved": round(con_gbs, 2), "frac": round(con_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(con_ms, 5)},
-            "stage_ms_per_step": stage_tab,
+            "repeats": repeats, "timed_s": round(dt, 4),
+            "value_single_context": round(value_single, 3) if value_single else None,
+            "rank_s": {"render": [round(x[0], 4) for x in per_rank], "all_reduce": [round(x[1], 5) for x in per_rank]},
+            "traced_mrays_per_s": round(traced * nshare / dt / 1e6, 2),
+            "rays_per_step": {"extend": ctr["extend_rays"] // frames_timed, "connect": ctr["connect_rays"] // frames_timed},
+            "roofline": roof, "connect_roofline": con, "stage_ms_per_step": stage_tab,
             "host_build_s": round(build_s, 2), "accum_rgb_sum": checksum,
         }
         if not args.no_cpu_baseline and world == 1:

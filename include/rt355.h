@@ -73,8 +73,18 @@ typedef struct RtStageTimes {
     int64_t generate_launches, extend_launches, shade_launches, compact_launches, connect_launches, accumulate_launches;
 } RtStageTimes;
 
+/* Which kernels a context runs for the uploaded scene (chosen at rt_upload_scene; bench.py names the roofline's kernel from it). */
+typedef struct RtKernelInfo {
+    int32_t layout;               /* 0 = the reference arrays as uploaded, 1 = derived pair / quad / triangle records */
+    int32_t persist, persist4;    /* persistent-wavefront traversal over the BVH2 / BVH4 (one BLAS)                  */
+    int32_t stack_entries;        /* LDS traversal stack entries per lane                                             */
+    int32_t persist_grid, persist_grid_connect, shade_grid;   /* workgroups of the persistent launches                */
+    int32_t n_blas;
+} RtKernelInfo;
+
 const char* rt_last_error(void);
 int rt_device_count(void);
+int rt_kernel_info(RtCtx* ctx, RtKernelInfo* out);
 
 /* new Buffer(...) x11 + new Kernel(...) x6 (renderer.cpp:145-157, :218-223). */
 int rt_create(const RtConfig* cfg, RtCtx** out);

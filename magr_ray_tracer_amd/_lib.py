@@ -44,6 +44,9 @@ Config = np.dtype([(n, "<i4") for n in ("width", "height", "y0", "y1", "max_boun
                                          "russian_roulette", "filter_fireflies", "device", "extend_variant", "profile")] +
                   [("reserved", "<i4", 3)])
 
+KernelInfo = np.dtype([(n, "<i4") for n in ("layout", "persist", "persist4", "stack_entries", "persist_grid", "persist_grid_connect",
+                                             "shade_grid", "n_blas")])
+
 _SIZES = {"Ray": (Ray, 128), "ShadowRay": (ShadowRay, 96), "Material": (Material, 80), "Primitive": (Primitive, 128),
           "Camera": (Camera, 128), "Settings": (Settings, 40), "BVHNode2": (BVHNode2, 48), "BVHNode4": (BVHNode4, 160),
           "BVHInstance": (BVHInstance, 68), "TLASNode": (TLASNode, 48), "ShadowRecord": (ShadowRecord, 48), "Config": (Config, 64)}
@@ -57,7 +60,7 @@ PRIM_SPHERE, PRIM_PLANE, PRIM_TRIANGLE = 0, 1, 2
 MAX_BOUNCES = 7
 
 DEVICE_SYMBOLS = [
-    "rt_last_error", "rt_device_count", "rt_create", "rt_destroy", "rt_upload_scene", "rt_set_seeds", "rt_seed_default",
+    "rt_last_error", "rt_device_count", "rt_kernel_info", "rt_create", "rt_destroy", "rt_upload_scene", "rt_set_seeds", "rt_seed_default",
     "rt_get_seeds", "rt_bind_accum", "rt_accum_device_ptr", "rt_stream", "rt_reset", "rt_render", "rt_synchronize", "rt_focus",
     "rt_read_accum", "rt_write_accum", "rt_postproc", "rt_read_counters", "rt_reset_counters", "rt_read_stage_times", "rt_reset_stage_times", "rt_set_profile",
     "rt_stage_begin_frame", "rt_stage_generate", "rt_stage_extend", "rt_stage_shade", "rt_stage_connect",
@@ -96,6 +99,7 @@ def device_lib():
         vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
         lib.rt_last_error.restype = C.c_char_p
         lib.rt_create.argtypes = [vp, C.POINTER(vp)]
+        lib.rt_kernel_info.argtypes = [vp, vp]
         lib.rt_destroy.argtypes = [vp]
         lib.rt_upload_scene.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32]
         lib.rt_set_seeds.argtypes = [vp, vp, i64]

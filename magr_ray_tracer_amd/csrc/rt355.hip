@@ -63,6 +63,14 @@ enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_COMPACT, ST_CONNECT, ST_ACCUM };
 
 extern "C" const char* rt_last_error(void) { return g_err.c_str(); }
 extern "C" int rt_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+extern "C" int rt_kernel_info(RtCtx* ctx, RtKernelInfo* out)
+{
+    if (!ctx || !out) return fail(RT_E_INVALID, "rt_kernel_info: null argument");
+    if (!ctx->sceneLoaded) return fail(RT_E_INVALID, "rt_kernel_info: no scene uploaded");
+    *out = RtKernelInfo{ ctx->layout, ctx->persist ? 1 : 0, ctx->persist4 ? 1 : 0, ctx->stackEntries, ctx->persistGrid, ctx->persistGridConnect,
+                         ctx->shadeGrid, ctx->sc.nBlas };
+    return RT_OK;
+}
 
 template <class T> static int dalloc(std::vector<void*>& bag, T** p, size_t count)
 {
@@ -313,6 +321,19 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         const uint32_t lr = tlas[i].leftRight;
         if (lr == 0) { if (tlas[i].BLASidx >= (uint32_t)nBlas) return fail(RT_E_INVALID, "tlas node %d: BLASidx out of range", i); }
         else if ((lr & 0xffffu) >= (uint32_t)nTlas || (lr >> 16) >= (uint32_t)nTlas) return fail(RT_E_INVALID, "tlas node %d: child out of range", i);
+    }
+    {   // walk the TLAS from node 0: a back reference would make traverse_tlas spin forever, and its private stack holds
+        // RT_TLAS_STACK entries (the ordered descent keeps at most one pending sibling per level, so depth bounds the stack)
+        std::vector<std::pair<uint32_t, int>> st; st.push_back({ 0u, 0 });
+        size_t visited = 0; int depth = 0;
+        while (!st.empty()) {
+            auto [i, d] = st.back(); st.pop_back();
+            if (++visited > (size_t)nTlas) return fail(RT_E_INVALID, "tlas: a node is reachable twice (cycle or shared child)");
+            depth = std::max(depth, d);
+            const uint32_t lr = tlas[i].leftRight;
+            if (lr != 0) { st.push_back({ lr & 0xffffu, d + 1 }); st.push_back({ lr >> 16, d + 1 }); }
+        }
+        if (depth > RT_TLAS_STACK) return fail(RT_E_UNSUPPORTED, "tlas: depth %d exceeds the %d-entry traversal stack", depth, RT_TLAS_STACK);
     }
     // The reference kernels give BVH2 32 and BVH4 64 stack entries (bvh.cl:15,57) and overflow silently beyond that
     // (SBVH trees at alpha = 0 do get deeper than 32); this library sizes the LDS stack to the tree, up to 64 entries.
@@ -595,7 +616,7 @@ extern "C" int rt_stage_generate(RtCtx* ctx, const RtCamera* cam, const RtSettin
 extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
 {
     int rc = need_scene(ctx, "rt_stage_extend"); if (rc) return rc;
-    if (bounce < 0 || bounce >= RT_MAX_BOUNCES + 1) return fail(RT_E_INVALID, "rt_stage_extend: bounce %d", bounce);
+    if (bounce < 0 || bounce > ctx->cfg.max_bounces) return fail(RT_E_INVALID, "rt_stage_extend: bounce %d outside [0, %d]", bounce, ctx->cfg.max_bounces);
     if (ctx->persist || ctx->persist4) { // a queue head is good for one launch per frame; re-arm it if this stage is run again
         if (ctx->cursorUsed[bounce]) HIPCHK(hipMemsetAsync(ctx->q.cursor + bounce, 0, sizeof(int32_t), ctx->stream));
         ctx->cursorUsed[bounce] = true;
@@ -623,7 +644,8 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
 extern "C" int rt_stage_shade(RtCtx* ctx, int32_t bounce)
 {
     int rc = need_scene(ctx, "rt_stage_shade"); if (rc) return rc;
-    if (bounce < 0 || bounce >= RT_MAX_BOUNCES) return fail(RT_E_INVALID, "rt_stage_shade: bounce %d", bounce);
+    // the shadow queue and the counter rows are sized by cfg.max_bounces, not by the compile-time maximum
+    if (bounce < 0 || bounce >= ctx->cfg.max_bounces) return fail(RT_E_INVALID, "rt_stage_shade: bounce %d outside [0, %d)", bounce, ctx->cfg.max_bounces);
     // The scan state of bounce b is armed by generate (b = 0) or by shade(b-1); re-arm it by hand when this
     // stage is run out of sequence (stage-level API used by the tests) or twice for the same bounce.
     if (ctx->shadeRun[bounce] || (bounce > 0 && !ctx->shadeRun[bounce - 1]) || (bounce == 0 && !ctx->generated)) {
@@ -645,7 +667,7 @@ extern "C" int rt_stage_shade(RtCtx* ctx, int32_t bounce)
 extern "C" int rt_stage_connect(RtCtx* ctx, int32_t b0, int32_t b1)
 {
     int rc = need_scene(ctx, "rt_stage_connect"); if (rc) return rc;
-    if (b0 < 0 || b1 < b0 || b1 >= RT_MAX_BOUNCES) return fail(RT_E_INVALID, "rt_stage_connect: bounce range [%d,%d]", b0, b1);
+    if (b0 < 0 || b1 < b0 || b1 >= ctx->cfg.max_bounces) return fail(RT_E_INVALID, "rt_stage_connect: bounce range [%d,%d] outside [0, %d)", b0, b1, ctx->cfg.max_bounces);
     const int cap = ctx->nPix * (b1 - b0 + 1);
     if (ctx->persist || ctx->persist4) {
         const int ci = (RT_MAX_BOUNCES + 2) + b0;
@@ -825,7 +847,7 @@ static int read_count(RtCtx* ctx, const int32_t* dev, int32_t* out)
 extern "C" int rt_debug_get_rays(RtCtx* ctx, int32_t bounce, RtRay* out, int32_t capacity, int32_t* n)
 {
     int rc = need_scene(ctx, "rt_debug_get_rays"); if (rc) return rc;
-    if (!n || bounce < 0 || bounce > RT_MAX_BOUNCES) return fail(RT_E_INVALID, "rt_debug_get_rays: bad argument");
+    if (!n || bounce < 0 || bounce > ctx->cfg.max_bounces) return fail(RT_E_INVALID, "rt_debug_get_rays: bad argument");
     HIPCHK(hipSetDevice(ctx->cfg.device));
     if ((rc = read_count(ctx, ctx->q.nRays + bounce, n))) return rc;
     if (!out) return RT_OK;
@@ -841,7 +863,7 @@ extern "C" int rt_debug_get_rays(RtCtx* ctx, int32_t bounce, RtRay* out, int32_t
 }
 extern "C" int rt_debug_set_rays(RtCtx* ctx, int32_t bounce, const RtRay* in, int32_t n)
 {
-    if (!ctx || !in || n < 0 || n > ctx->nPix || bounce < 0 || bounce > RT_MAX_BOUNCES) return fail(RT_E_INVALID, "rt_debug_set_rays: bad argument");
+    if (!ctx || !in || n < 0 || n > ctx->nPix || bounce < 0 || bounce > ctx->cfg.max_bounces) return fail(RT_E_INVALID, "rt_debug_set_rays: bad argument");
     HIPCHK(hipSetDevice(ctx->cfg.device));
     int rc = ray_io(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -857,7 +879,7 @@ extern "C" int rt_debug_set_rays(RtCtx* ctx, int32_t bounce, const RtRay* in, in
 }
 extern "C" int rt_debug_get_shadow(RtCtx* ctx, int32_t b0, int32_t b1, RtShadowRecord* out, int32_t capacity, int32_t* n)
 {
-    if (!ctx || !n || b0 < 0 || b1 < b0 || b1 >= RT_MAX_BOUNCES) return fail(RT_E_INVALID, "rt_debug_get_shadow: bad argument");
+    if (!ctx || !n || b0 < 0 || b1 < b0 || b1 >= ctx->cfg.max_bounces) return fail(RT_E_INVALID, "rt_debug_get_shadow: bad argument");
     HIPCHK(hipSetDevice(ctx->cfg.device));
     int32_t lo = 0, hi = 0, rc;
     if ((rc = read_count(ctx, ctx->q.nShadow + b0, &lo))) return rc;

@@ -150,6 +150,25 @@ RT_FORCEINLINE float slab(const TRay& r, float4 bmin, float4 bmax) // bvh.cl:3-1
     return (tmax >= tmin && tmin < r.t && tmax > 0) ? tmin : kFar;
 }
 
+// Any-hit (connect) form of the same test: `hit` is exactly the reference's "visit this child" condition (slab() < t_light; in an
+// occlusion traversal ray.t stays t_light until the first accepted primitive ends it, bvh.cl:25,40), and the exit distance comes
+// for free.  Whether a shadow ray is occluded does not depend on the ORDER in which the children that pass this test are visited
+// (a node is reached iff all its ancestors pass, whatever the order; the first accepted primitive returns), so connect is free to
+// pick its own: the child the ray leaves LATER first - nearer the light, where most occluders of this kind of scene sit - finds
+// an occluder after 27.6 instead of 34.9 node visits per shadow ray on the bench scene (tools/lab/anyhit_lab.c; 85 % of its
+// shadow rays are occluded), with the accumulator unchanged bit for bit.
+RT_FORCEINLINE bool slab_any(const TRay& r, float4 bmin, float4 bmax, float& exitT)
+{
+    float tx1 = (bmin.x - r.ox) * r.rx, tx2 = (bmax.x - r.ox) * r.rx;
+    float tmin = fminf(tx1, tx2), tmax = fmaxf(tx1, tx2);
+    float ty1 = (bmin.y - r.oy) * r.ry, ty2 = (bmax.y - r.oy) * r.ry;
+    tmin = fmaxf(tmin, fminf(ty1, ty2)); tmax = fminf(tmax, fmaxf(ty1, ty2));
+    float tz1 = (bmin.z - r.oz) * r.rz, tz2 = (bmax.z - r.oz) * r.rz;
+    tmin = fmaxf(tmin, fminf(tz1, tz2)); tmax = fminf(tmax, fmaxf(tz1, tz2));
+    exitT = tmax;
+    return tmax >= tmin && tmin < r.t && tmax > 0;
+}
+
 RT_FORCEINLINE void test_prim(const DevScene& sc, int idx, TRay& r) // primitives.cl:11-89
 {
     const RtPrimitive* p = sc.prims + idx;
@@ -223,6 +242,14 @@ RT_FORCEINLINE int traverse_bvh2(const DevScene& sc, TRay& r, uint32_t root, uin
         }
         wc.node++;
         uint32_t c1 = fc.x, c2 = fc.x + 1;
+        if (OCC) {   // any-hit: own visit order (see slab_any)
+            float x1, x2;
+            const bool h1 = slab_any(r, ld4(nodes[c1].aabbMin), ld4(nodes[c1].aabbMax), x1), h2 = slab_any(r, ld4(nodes[c2].aabbMin), ld4(nodes[c2].aabbMax), x2);
+            if (h1 && h2) { const bool firstIs2 = x2 > x1; node = firstIs2 ? c2 : c1; STK(sp) = firstIs2 ? c1 : c2; sp++; }
+            else if (h1 || h2) node = h1 ? c1 : c2;
+            else { if (sp == 0) break; node = STK(--sp); }
+            continue;
+        }
         float d1 = slab(r, ld4(nodes[c1].aabbMin), ld4(nodes[c1].aabbMax));
         float d2 = slab(r, ld4(nodes[c2].aabbMin), ld4(nodes[c2].aabbMax));
         if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t c = c1; c1 = c2; c2 = c; }
@@ -295,9 +322,18 @@ RT_FORCEINLINE int traverse_bvh2_packed(const DevScene& sc, TRay& r, uint32_t ro
         wc.node++;
         const float4* p = sc.pairs + (size_t)cur * 4;
         const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
+        if (OCC) {   // any-hit: own visit order (see slab_any)
+            float x1, x2;
+            const bool h1 = slab_any(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f), x1);
+            const bool h2 = slab_any(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f), x2);
+            if (h1 && h2) { const bool firstIs2 = x2 > x1; cur = firstIs2 ? e2 : e1; STK(sp) = firstIs2 ? e1 : e2; sp++; }
+            else if (h1 || h2) cur = h1 ? e1 : e2;
+            else { if (sp == 0) break; cur = STK(--sp); }
+            continue;
+        }
         float d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
         float d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
-        uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
         if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t e = e1; e1 = e2; e2 = e; }
         if (d1 >= tLight) {
             if (sp == 0) break;
@@ -674,17 +710,27 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
                 wc.node++;
                 const float4* p = sc.pairs + (size_t)cur * 4;
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                float d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
-                float d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
                 uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
-                if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t e = e1; e1 = e2; e2 = e; }
-                if (d1 >= tLight) {
-                    if (sp == 0) done = true;
+                if (OCC) {   // any-hit: the child the ray leaves later first (see slab_any); no `steps`, no near / far sort
+                    float x1, x2;
+                    const bool h1 = slab_any(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f), x1);
+                    const bool h2 = slab_any(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f), x2);
+                    if (h1 && h2) { const bool firstIs2 = x2 > x1; cur = firstIs2 ? e2 : e1; STK(sp) = firstIs2 ? e1 : e2; sp++; }
+                    else if (h1 || h2) cur = h1 ? e1 : e2;
+                    else if (sp == 0) done = true;
                     else cur = STK(--sp);
                 } else {
-                    steps++;
-                    cur = e1;
-                    if (d2 < tLight) { STK(sp) = e2; sp++; steps++; }
+                    float d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
+                    float d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
+                    if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t e = e1; e1 = e2; e2 = e; }
+                    if (d1 >= tLight) {
+                        if (sp == 0) done = true;
+                        else cur = STK(--sp);
+                    } else {
+                        steps++;
+                        cur = e1;
+                        if (d2 < tLight) { STK(sp) = e2; sp++; steps++; }
+                    }
                 }
             }
             if (done) {

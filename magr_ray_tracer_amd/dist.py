@@ -7,6 +7,9 @@ accumulator per render (BASELINE.json north star: "samples partition across the 
   shard="bands":   rank r renders rows [r*H/N, (r+1)*H/N) with seeds[a..b) of the frame's stream; the
                    all_reduce(SUM) of the zero-padded full-frame accumulators is exact (adds zeros) and
                    equals a gather.
+  shard="ibands":  the same with the frame cut into bands of `band_rows` rows dealt out round-robin (band k -> rank k mod N;
+                   SURVEY.md §8(e): "bands of 16-32 rows round-robin" against sky-vs-geometry imbalance; BASELINE config 4's
+                   "screen-tile shard").  A rank runs one context per band it owns, interleaved like lanes.
 
 Lanes: the sample partition applied once more INSIDE a GPU.  Every launch of a frame ends in a tail of a few long rays during which
 most of the chip idles, and consecutive frames of one accumulation cannot overlap (each continues the RNG state of the one before).
@@ -46,6 +49,23 @@ def plan(shard, width, height, rank, world, lane=0, lanes=1):
     return dict(y0=y0, y1=y1, seed_first=first, seed_count=n)
 
 
+def interleaved_bands(height, rank, world, band_rows=None):
+    """Row bands [y0, y1) of rank `rank` under the round-robin plan: band k (rows [k*b, (k+1)*b)) belongs to rank k mod world.
+    Default band height: a quarter of a contiguous band, at least 8 rows (so that a rank owns ~4 bands spread over the frame)."""
+    b = band_rows or max(8, -(-height // (world * 4)))
+    return [(y, min(y + b, height)) for k, y in enumerate(range(0, height, b)) if k % world == rank]
+
+
+def plans(shard, width, height, rank, world, lane=0, lanes=1, band_rows=None):
+    """All contexts of this rank (and lane): one plan for "samples" / "bands", one per owned band for "ibands"."""
+    if shard != "ibands":
+        return [plan(shard, width, height, rank, world, lane, lanes)]
+    if lanes != 1:
+        raise ValueError("lanes partition samples; the band plans run one context per band")
+    return [dict(y0=y0, y1=y1, seed_first=y0 * width, seed_count=(y1 - y0) * width)
+            for y0, y1 in interleaved_bands(height, rank, world, band_rows)]
+
+
 def lane_frames(frames, lanes):
     """How many of `frames` 1-spp frames each lane renders (the first frames % lanes lanes take one more)."""
     return [frames // lanes + (1 if m < frames % lanes else 0) for m in range(lanes)]
@@ -54,8 +74,12 @@ def lane_frames(frames, lanes):
 class Lanes:
     """`lanes` Device contexts of one rank rendering disjoint sample streams of the same frame concurrently (see the module text)."""
 
-    def __init__(self, lanes, make_device, seeds_for):
-        """make_device(lane) -> an uploaded Device; seeds_for(lane) -> its uint32 seed slice."""
+    def __init__(self, lanes, make_device=None, seeds_for=None):
+        """Either a list of uploaded, seeded Devices, or a count with make_device(lane) -> an uploaded Device and
+        seeds_for(lane) -> its uint32 seed slice."""
+        if make_device is None:
+            self.devs = list(lanes)
+            return
         self.devs = [make_device(m) for m in range(lanes)]
         for m, d in enumerate(self.devs):
             d.set_seeds(seeds_for(m))
@@ -63,9 +87,10 @@ class Lanes:
     def __len__(self):
         return len(self.devs)
 
-    def render(self, cam, frames):
-        """`frames` frames in total, interleaved over the lanes so that their kernels overlap on the GPU."""
-        todo = lane_frames(frames, len(self.devs))
+    def render(self, cam, frames, each=False):
+        """`frames` frames in total, interleaved over the lanes so that their kernels overlap on the GPU (each=True: `frames`
+        frames on EVERY context - the band plans, where the contexts are parts of one frame)."""
+        todo = [frames] * len(self.devs) if each else lane_frames(frames, len(self.devs))
         for f in range(max(todo)):
             for m, d in enumerate(self.devs):
                 if f < todo[m]:

@@ -60,6 +60,20 @@ class Device:
             P(sa.lights) if len(sa.lights) else None, len(sa.lights), P(nodes), len(nodes), P(sa.primIdx), len(sa.primIdx),
             P(sa.tlas), len(sa.tlas), P(sa.blas), len(sa.blas)))
 
+    def kernel_info(self):
+        """Which traversal kernels this context runs for the uploaded scene (rt_kernel_info)."""
+        k = np.zeros((), dtype=_lib.KernelInfo)
+        self._chk(self._lib.rt_kernel_info(self._h, k.ctypes.data_as(C.c_void_p)))
+        return {n: int(k[n]) for n in k.dtype.names}
+
+    def extend_kernel_name(self):
+        k = self.kernel_info()
+        if k["persist4"]:
+            return "k_trace_persist4<false>"
+        if k["persist"]:
+            return "k_trace_persist<false>"
+        return "k_extend<%s, %d>" % ("RT_ACCEL_BVH4" if self.accel == _lib.ACCEL_BVH4 else "RT_ACCEL_BVH2", k["layout"])
+
     def set_seeds(self, seeds):
         s = np.ascontiguousarray(seeds, dtype=np.uint32)
         self._chk(self._lib.rt_set_seeds(self._h, _lib.ptr(s), s.size))

@@ -43,10 +43,10 @@ WORKER = textwrap.dedent("""
     s, view = scenes.cube_scene()
     sa = s.arrays()
     cam = scenes.camera_for(view, W, H)
-    p = rdist.plan(shard, W, H, rank, world)
     o = Oracle(sa, W, H)
-    seeds = seed_stream(p["seed_first"], p["seed_count"])
-    acc, *_ = o.render(cam, frames, seeds=seeds, y0=p["y0"], y1=p["y1"])
+    acc = np.zeros((H, W, 4), np.float32)
+    for p in rdist.plans(shard, W, H, rank, world, band_rows=5 if shard == "ibands" else None):   # one context per owned band
+        o.render(cam, frames, accum=acc, seeds=seed_stream(p["seed_first"], p["seed_count"]), y0=p["y0"], y1=p["y1"])
     t = torch.from_numpy(acc)
     rdist.reduce_accumulator(t)
     if rank == 0:
@@ -56,7 +56,7 @@ WORKER = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("shard", ["bands", "samples"])
+@pytest.mark.parametrize("shard", ["bands", "samples", "ibands"])
 def test_two_ranks_gloo_reduce(tmp_path, shard):
     from magr_ray_tracer_amd import scenes
     from oracle.oracle_py import Oracle, seed_stream
@@ -75,10 +75,16 @@ def test_two_ranks_gloo_reduce(tmp_path, shard):
     o = Oracle(sa, W, H)
     exp = np.zeros((H, W, 4), np.float32)
     for r in range(2):
-        p = rdist.plan(shard, W, H, r, 2)
-        part, *_ = o.render(cam, frames, seeds=seed_stream(p["seed_first"], p["seed_count"]), y0=p["y0"], y1=p["y1"])
+        part = np.zeros((H, W, 4), np.float32)
+        for p in rdist.plans(shard, W, H, r, 2, band_rows=5 if shard == "ibands" else None):
+            o.render(cam, frames, accum=part, seeds=seed_stream(p["seed_first"], p["seed_count"]), y0=p["y0"], y1=p["y1"])
         exp = exp + part          # two addends: the sum is order-independent, so gloo's reduction must match bit for bit
     assert np.array_equal(got, exp)
+    if shard == "ibands":
+        # bands of 5 rows dealt out round-robin: the two ranks' rows interleave and together cover the frame exactly once; a band
+        # renders with the frame's own seed slice, so the result equals the oracle rendering the same bands one after another
+        rows = sorted(y for r in range(2) for y0, y1 in rdist.interleaved_bands(H, r, 2, 5) for y in range(y0, y1))
+        assert rows == list(range(H)) and rdist.interleaved_bands(H, 0, 2, 5)[:2] == [(0, 5), (10, 15)]
     if shard == "bands":
         # zero-padded reduce == gather of the bands
         p0, p1 = rdist.plan(shard, W, H, 0, 2), rdist.plan(shard, W, H, 1, 2)

@@ -29,9 +29,14 @@ def _pair(scene_fn, Wd, Hd, variant, y0=0, y1=None):
 
 
 def _ctr_equal(dev, e, c):
+    """extend: every work counter equals the oracle's (same visit order as the reference).  connect is an any-hit traversal with
+    its own visit order inside a BLAS (rt355_kernels.h slab_any): whether a ray is occluded - hence the accumulator - does not depend
+    on it, the node / triangle counts do; rays, TLAS and instance visits are still the reference's."""
     for k in ("rays", "tlas_visits", "inst_visits", "node_visits", "prim_tests"):
         assert dev["extend_" + k] == e[k], ("extend_" + k, dev["extend_" + k], e[k])
+    for k in ("rays", "tlas_visits", "inst_visits"):
         assert dev["connect_" + k] == c[k], ("connect_" + k, dev["connect_" + k], c[k])
+    assert (dev["connect_node_visits"] > 0) == (c["node_visits"] > 0)
 
 
 @pytest.mark.parametrize("scene", list(TRI_SCENES))
@@ -838,3 +843,113 @@ def test_lanes_interleaved_sample_streams_match_oracle():
     assert not bits_equal(single, total) and abs(float(single[..., :3].sum()) / float(total[..., :3].sum()) - 1) < 0.05
     one.close()
     g.close()
+
+
+# ---- round 2 -----------------------------------------------------------------------------------------------------------------
+def test_bench_starts_its_own_ranks_two_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` from a bare shell (no torch.distributed.run): the parent spawns the two ranks itself.  Rehearsal
+    form for a 1-GPU box (--same-device --backend gloo; RCCL refuses two ranks on one device).  The reduced accumulator must equal
+    the sum of the two ranks' sample streams rendered one after the other in this process, bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    Wd, Hd, steps = 640, 360, 4
+    dump = tmp_path / "acc.npy"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--steps", str(steps),
+           "--warmup", "0", "--lanes", "1", "--no-cpu-baseline", "--no-repeat", "--width", str(Wd), "--height", str(Hd), "--detail", "0.2",
+           "--dump-accum", str(dump)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == steps and line["repeats"] == 1
+    assert len(line["rank_s"]["render"]) == 2 and len(line["rank_s"]["all_reduce"]) == 2 and line["value"] > 0
+    assert line["roofline"]["kernel"].startswith("extend = k_trace_persist<false>") and line["roofline"]["gather"]["frac"] > 0
+    got = np.load(dump)
+    s, view = scenes.sponza_class(0.2)
+    sa = s.arrays(bvh4=False)
+    cam = scenes.camera_for(view, Wd, Hd)
+    exp = np.zeros((Hd, Wd, 4), np.float32)
+    for rank in range(2):
+        d = Device(Wd, Hd, **DEFAULT)
+        d.upload(sa)
+        if rank == 0:
+            cam["focalLength"] = d.focus(Wd // 2, Hd // 2, cam)
+        d.set_seeds(seed_stream(rank * Wd * Hd, Wd * Hd))
+        d.render(cam, steps)
+        exp = exp + d.read_accum()
+        d.close()
+    assert_bits(got, exp, "2-rank reduced accumulator vs the two sample streams")
+    # a failing rank must surface as a non-zero exit code of the launcher
+    bad = subprocess.run(cmd[:-2] + ["--shard", "nonsense"], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert bad.returncode != 0
+
+
+def test_bench_scene_1080p_band_vs_oracle_counters_equal():
+    """The bench workload itself - sponza_class(1.0), 264,946 triangles, tree depth 21 (its own LDS stack size, occupancy and
+    persistent grid), 1920x1080 - against the oracle on a 16-row band: accumulator and RNG state bit for bit, extend work counters
+    equal (connect runs its own any-hit order: ray count equal)."""
+    Wd, Hd, y0, y1 = 1920, 1080, 532, 548
+    s, view = scenes.sponza_class(1.0)
+    sa = s.arrays(bvh4=False)
+    cam = scenes.camera_for(view, Wd, Hd)
+    o = Oracle(sa, Wd, Hd, **DEFAULT)
+    d = Device(Wd, Hd, y0=y0, y1=y1, **DEFAULT)
+    d.upload(sa)
+    info = d.kernel_info()
+    assert info["persist"] == 1 and info["layout"] == 1 and info["stack_entries"] >= 22
+    cam["focalLength"] = d.focus(Wd // 2, Hd // 2, cam)
+    ref, seeds, e, c = o.render(cam, 2, y0=y0, y1=y1)
+    d.seed_default()
+    d.render(cam, 2)
+    assert_bits(d.read_accum(), ref, "bench scene band vs oracle")
+    assert np.array_equal(d.get_seeds(), seeds)
+    dc = d.counters()
+    for k in ("rays", "tlas_visits", "inst_visits", "node_visits", "prim_tests"):
+        assert dc["extend_" + k] == e[k], (k, dc["extend_" + k], e[k])
+    assert dc["connect_rays"] == c["rays"]
+    d.close()
+
+
+def test_stage_entry_points_respect_the_contexts_max_bounces():
+    """Shadow queue and counter rows are sized by cfg.max_bounces: a stage call beyond it must be refused, not written past them."""
+    sa, cam, o, d = _pair(scenes.cube_scene, 64, 36, dict(DEFAULT, max_bounces=2))
+    d.seed_default()
+    d.render(cam, 1)
+    for fn, args in ((d.stage_shade, (3,)), (d.stage_shade, (2,)), (d.stage_connect, (0, 6)), (d.stage_connect, (2, 2)), (d.stage_extend, (3,)),
+                     (d.get_shadow, (0, 2))):
+        with pytest.raises(RtError):
+            fn(*args)
+    d.stage_connect(0, 1)
+    d.close()
+
+
+def test_upload_rejects_tlas_cycles_and_overdeep_tlas():
+    s, view = scenes.two_blas_scene(alpha=1.0, n=6)
+    sa = s.arrays()
+    d = Device(32, 18, **DEFAULT)
+    d.upload(sa)
+    import copy
+    bad = copy.copy(sa)
+    bad.tlas = sa.tlas.copy()
+    root = int(np.nonzero(bad.tlas["leftRight"] != 0)[0][0])
+    bad.tlas["leftRight"][root] = (root << 16) | (int(bad.tlas["leftRight"][root]) & 0xffff)     # right child = the node itself
+    with pytest.raises(RtError, match="reachable twice|cycle"):
+        d.upload(bad)
+    # a 40-deep chain of interior nodes: deeper than the 32-entry TLAS stack of traverse_tlas (tlas.cl:42)
+    deep = copy.copy(sa)
+    n = 41
+    t = np.zeros(2 * n + 1, dtype=sa.tlas.dtype)
+    for i in range(n):                       # node i: left = leaf n + i, right = node i + 1 (the last one: leaf 2n)
+        t["leftRight"][i] = (((i + 1) if i < n - 1 else 2 * n) << 16) | (n + i)
+        t["aabbMin"][i], t["aabbMax"][i] = sa.tlas["aabbMin"][0], sa.tlas["aabbMax"][0]
+    for i in range(n, 2 * n + 1):
+        t["leftRight"][i], t["BLASidx"][i] = 0, i % 2
+        t["aabbMin"][i], t["aabbMax"][i] = sa.tlas["aabbMin"][0], sa.tlas["aabbMax"][0]
+    deep.tlas = t
+    with pytest.raises(RtError, match="depth"):
+        d.upload(deep)
+    d.upload(sa)           # the context is still usable
+    d.close()
