@@ -54,7 +54,7 @@ struct RtCtx {
     bool shadeRun[RT_MAX_BOUNCES + 1] = {};           // shade(b) launched since the last k_begin_frame
     bool generated = false;                           // generate launched since the last k_begin_frame
     int stackEntries = RT_BVH2_STACK, persistGrid = 0, persistGridConnect = 0;
-    PersistTune tune{ 112, 24, 6, 8 }, tuneConnect{ 128, 32, 6, 8 }, tune4{ 64, 20, 6, 8 };   // extend (BVH2), connect, extend (BVH4): measured optima (tools/tune_extend.sh, tune_connect.sh, tune_persist.sh)
+    PersistTune tune{ 112, 24, 6, 8, 0 }, tuneConnect{ 128, 32, 6, 8, 0 }, tune4{ 64, 20, 6, 8, 0 };   // extend (BVH2), connect, extend (BVH4): measured optima (tools/tune_extend.sh, tune_connect.sh, tune_persist.sh)
     float4* dPostF = nullptr; uchar4* dPostB = nullptr;   // post-processing outputs (lazy)
     int32_t* dSteps = nullptr;   // per-ray `steps` buffer, only bound while rt_debug_enable_steps is on
     int shadeGrid = 1024;   // workgroups of k_shade (what the CUs hold at once; the kernel does not depend on it); set in rt_create
@@ -441,6 +441,18 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
             std::vector<uint32_t> roots((size_t)nBlas);
             for (int32_t b = 0; b < nBlas; b++) roots[b] = entry(blas[b].bvhIdx);
             rc = upload(ctx, &sc.pairs, pairs.data(), pairs.size());
+            if (rc == RT_OK && getenv("RT355_TWO_LEVEL")) {   // two-level records (traverse_bvh2_packed2): pair of k, then the pairs of its children
+                std::vector<float4> p2(std::max<size_t>(order.size(), 1) * 12, make_float4(0, 0, 0, 0));
+                for (size_t k = 0; k < order.size(); k++) {
+                    for (int v = 0; v < 4; v++) p2[k * 12 + v] = pairs[k * 4 + v];
+                    for (int c = 0; c < 2; c++) {
+                        uint32_t e; memcpy(&e, c == 0 ? &pairs[k * 4 + 3].x : &pairs[k * 4 + 3].y, 4);
+                        if (!(e & 0x80000000u)) for (int v = 0; v < 4; v++) p2[k * 12 + 4 + c * 4 + v] = pairs[(size_t)e * 4 + v];
+                    }
+                }
+                rc = upload(ctx, &sc.pairs2, p2.data(), p2.size());
+                ctx->tune.twoLevel = atoi(getenv("RT355_TWO_LEVEL"));
+            }
             if (rc == RT_OK) rc = upload(ctx, &sc.triRecs, recs.data(), recs.size());
             if (rc == RT_OK) rc = upload(ctx, &sc.rootEntry, roots.data(), roots.size());
             if (rc == RT_OK) ctx->layout = 1;
@@ -517,12 +529,12 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner,leafK[,blocksPerCU]" (tuning aid)
             int a = 0, b = 0, c = 0, l = 0, d = 0;
             int k = sscanf(t, "%d,%d,%d,%d,%d", &a, &b, &c, &l, &d);
-            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = ctx->tuneConnect = ctx->tune4 = PersistTune{ a, b, c, l };
+            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) { const int tl = ctx->tune.twoLevel; ctx->tune = ctx->tuneConnect = ctx->tune4 = PersistTune{ a, b, c, l, 0 }; ctx->tune.twoLevel = tl; }
             if (k == 5 && d > 0) ctx->persistGrid = ctx->persistGridConnect = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount);
         }
         if (const char* t = getenv("RT355_TUNE_CONNECT")) { // same fields, connect launches only
             int a = 0, b = 0, c = 0, l = 0;
-            if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l };
+            if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l, 0 };
         }
     }
     ctx->sc = sc;
