@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--detail", type=float, default=1.0, help="sponza-class tessellation (1.0 = ~262k triangles)")
     ap.add_argument("--accel", choices=["bvh2", "bvh4"], default="bvh2")
     ap.add_argument("--shard", choices=["samples", "bands", "ibands"], default="samples")
-    ap.add_argument("--lanes", type=int, default=2, help="independent sample streams per GPU whose frames overlap (samples plan only; 1 = one context)")
+    ap.add_argument("--lanes", type=int, default=3, help="independent sample streams per GPU whose frames overlap (samples plan only; 1 = one context)")
     ap.add_argument("--extend-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stage launches with HIP events")

@@ -47,6 +47,8 @@ int rth_build_blas(RthScene* s, int startIdx, float alpha);
 int rth_set_build_threads(RthScene* s, int threads);
 int rth_build_bvh4(RthScene* s);            /* new BVH4(*bvh2) (scene.cpp:71)                    */
 int rth_build_tlas(RthScene* s);            /* new TLAS(*bvh2); Build() (renderer.cpp:12-13)     */
+/* BVH4::Convert + Collapse (bvh.cpp:695-787) on a caller-provided BVH2 node array, one BLAS rooted at node 0; out[n] */
+int rth_bvh4_from_nodes(const RtBVHNode2* nodes, int n, RtBVHNode4* out);
 int rth_set_instance_transform(RthScene* s, int blas, const float invT[16]); /* scene.cpp:82 (commented out there) */
 
 /* Borrowed views of the arrays (valid until the scene changes). */

@@ -68,7 +68,7 @@ DEVICE_SYMBOLS = [
 HOST_SYMBOLS = [
     "rth_last_error", "rth_scene_create", "rth_scene_destroy", "rth_add_material", "rth_add_texture", "rth_load_texture", "rth_add_sphere",
     "rth_add_plane", "rth_add_triangle", "rth_add_quad", "rth_add_triangles", "rth_build_blas", "rth_build_bvh4",
-    "rth_build_tlas", "rth_set_instance_transform", "rth_primitives", "rth_materials", "rth_textures", "rth_lights",
+    "rth_build_tlas", "rth_bvh4_from_nodes", "rth_set_instance_transform", "rth_primitives", "rth_materials", "rth_textures", "rth_lights",
     "rth_bvh2_nodes", "rth_bvh4_nodes", "rth_prim_idx", "rth_tlas_nodes", "rth_blas_nodes", "rth_bvh_stats", "rth_camera",
     "rth_renderer_create", "rth_renderer_destroy", "rth_renderer_init", "rth_renderer_set_camera", "rth_renderer_tick",
     "rth_renderer_read", "rth_renderer_camera", "rth_seed_stream", "rth_load_model", "rth_save_png",
@@ -158,6 +158,7 @@ def host_lib():
         lib.rth_build_bvh4.argtypes = [vp]
         lib.rth_set_build_threads.argtypes = [vp, i32]
         lib.rth_build_tlas.argtypes = [vp]
+        lib.rth_bvh4_from_nodes.argtypes = [vp, i32, vp]
         lib.rth_set_instance_transform.argtypes = [vp, i32, fp]
         for n in ("rth_primitives", "rth_materials", "rth_textures", "rth_lights", "rth_bvh2_nodes", "rth_bvh4_nodes",
                   "rth_prim_idx", "rth_tlas_nodes", "rth_blas_nodes"):

@@ -54,7 +54,7 @@ struct RtCtx {
     bool shadeRun[RT_MAX_BOUNCES + 1] = {};           // shade(b) launched since the last k_begin_frame
     bool generated = false;                           // generate launched since the last k_begin_frame
     int stackEntries = RT_BVH2_STACK, persistGrid = 0, persistGridConnect = 0;
-    PersistTune tune{ 112, 24, 6, 8, 0 }, tuneConnect{ 128, 32, 6, 8, 0 }, tune4{ 64, 20, 6, 8, 0 };   // extend (BVH2), connect, extend (BVH4): measured optima (tools/tune_extend.sh, tune_connect.sh, tune_persist.sh)
+    PersistTune tune{ 112, 24, 6, 8 }, tuneConnect{ 128, 32, 6, 8 }, tune4{ 64, 20, 6, 8 };   // extend (BVH2), connect, extend (BVH4): measured optima (tools/tune_extend.sh, tune_connect.sh, tune_persist.sh)
     float4* dPostF = nullptr; uchar4* dPostB = nullptr;   // post-processing outputs (lazy)
     int32_t* dSteps = nullptr;   // per-ray `steps` buffer, only bound while rt_debug_enable_steps is on
     int shadeGrid = 1024;   // workgroups of k_shade (what the CUs hold at once; the kernel does not depend on it); set in rt_create
@@ -441,18 +441,6 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
             std::vector<uint32_t> roots((size_t)nBlas);
             for (int32_t b = 0; b < nBlas; b++) roots[b] = entry(blas[b].bvhIdx);
             rc = upload(ctx, &sc.pairs, pairs.data(), pairs.size());
-            if (rc == RT_OK && getenv("RT355_TWO_LEVEL")) {   // two-level records (traverse_bvh2_packed2): pair of k, then the pairs of its children
-                std::vector<float4> p2(std::max<size_t>(order.size(), 1) * 12, make_float4(0, 0, 0, 0));
-                for (size_t k = 0; k < order.size(); k++) {
-                    for (int v = 0; v < 4; v++) p2[k * 12 + v] = pairs[k * 4 + v];
-                    for (int c = 0; c < 2; c++) {
-                        uint32_t e; memcpy(&e, c == 0 ? &pairs[k * 4 + 3].x : &pairs[k * 4 + 3].y, 4);
-                        if (!(e & 0x80000000u)) for (int v = 0; v < 4; v++) p2[k * 12 + 4 + c * 4 + v] = pairs[(size_t)e * 4 + v];
-                    }
-                }
-                rc = upload(ctx, &sc.pairs2, p2.data(), p2.size());
-                ctx->tune.twoLevel = atoi(getenv("RT355_TWO_LEVEL"));
-            }
             if (rc == RT_OK) rc = upload(ctx, &sc.triRecs, recs.data(), recs.size());
             if (rc == RT_OK) rc = upload(ctx, &sc.rootEntry, roots.data(), roots.size());
             if (rc == RT_OK) ctx->layout = 1;
@@ -529,12 +517,12 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner,leafK[,blocksPerCU]" (tuning aid)
             int a = 0, b = 0, c = 0, l = 0, d = 0;
             int k = sscanf(t, "%d,%d,%d,%d,%d", &a, &b, &c, &l, &d);
-            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) { const int tl = ctx->tune.twoLevel; ctx->tune = ctx->tuneConnect = ctx->tune4 = PersistTune{ a, b, c, l, 0 }; ctx->tune.twoLevel = tl; }
+            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = ctx->tuneConnect = ctx->tune4 = PersistTune{ a, b, c, l };
             if (k == 5 && d > 0) ctx->persistGrid = ctx->persistGridConnect = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount);
         }
         if (const char* t = getenv("RT355_TUNE_CONNECT")) { // same fields, connect launches only
             int a = 0, b = 0, c = 0, l = 0;
-            if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l, 0 };
+            if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l };
         }
     }
     ctx->sc = sc;
@@ -606,24 +594,33 @@ static int need_scene(RtCtx* ctx, const char* who)
 }
 static inline dim3 grid_for(int n) { return dim3((unsigned)std::max(1, (n + kBlock - 1) / kBlock)); }
 
+static void frame_state_reset(RtCtx* ctx)
+{
+    memset(ctx->cursorUsed, 0, sizeof ctx->cursorUsed);
+    memset(ctx->shadeRun, 0, sizeof ctx->shadeRun);
+    ctx->generated = false;
+}
 extern "C" int rt_stage_begin_frame(RtCtx* ctx)
 {
     if (!ctx) return fail(RT_E_INVALID, "rt_stage_begin_frame: null context");
     hipLaunchKernelGGL(k_begin_frame, dim3(1), dim3(256), 0, ctx->stream, ctx->q);
     HIPCHK(hipGetLastError());
-    memset(ctx->cursorUsed, 0, sizeof ctx->cursorUsed);
-    memset(ctx->shadeRun, 0, sizeof ctx->shadeRun);
-    ctx->generated = false;
+    frame_state_reset(ctx);
+    return RT_OK;
+}
+static int generate(RtCtx* ctx, const RtCamera* cam, const RtSettings* s, int beginFrame)
+{
+    if (beginFrame) frame_state_reset(ctx);
+    LAUNCH(ctx, ST_GENERATE, k_generate, grid_for(ctx->nPix), 0, ctx->q, *cam, s ? s->antiAliasing : 1, beginFrame);
+    HIPCHK(hipGetLastError());
+    ctx->primaryRays += (uint64_t)ctx->nPix;
+    ctx->generated = true;
     return RT_OK;
 }
 extern "C" int rt_stage_generate(RtCtx* ctx, const RtCamera* cam, const RtSettings* s)
 {
     if (!ctx || !cam) return fail(RT_E_INVALID, "rt_stage_generate: null argument");
-    LAUNCH(ctx, ST_GENERATE, k_generate, grid_for(ctx->nPix), 0, ctx->q, *cam, s ? s->antiAliasing : 1);
-    HIPCHK(hipGetLastError());
-    ctx->primaryRays += (uint64_t)ctx->nPix;
-    ctx->generated = true;
-    return RT_OK;
+    return generate(ctx, cam, s, 0);
 }
 extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
 {
@@ -716,8 +713,7 @@ extern "C" int rt_render(RtCtx* ctx, const RtCamera* cam, const RtSettings* sett
     const bool nee = ctx->cfg.shading == RT_SHADING_NEE, rr = ctx->cfg.russian_roulette != 0;
     const int renderBVH = settings ? settings->renderBVH : 0;
     for (int f = 0; f < frames; f++) {
-        if ((rc = rt_stage_begin_frame(ctx))) return rc;
-        if ((rc = rt_stage_generate(ctx, cam, settings))) return rc;
+        if ((rc = generate(ctx, cam, settings, 1))) return rc;   // the frame's counter reset rides in k_generate's first workgroup
         for (int b = 0; b < ctx->cfg.max_bounces; b++) {
             if ((rc = rt_stage_extend(ctx, b, renderBVH))) return rc;
             if (renderBVH) break;                                  // renderer.cpp:79

@@ -52,7 +52,6 @@ struct DevScene {
     const float4*        triRecs;    // [nIdx][3]    leaf-ordered triangle vertices + primitive id
     const uint32_t*      rootEntry;  // [nBlas]      encoded root of every instance
     const float4*        shadeRecs;  // [nPrims]     {N.xyz, bits(matIdx | (N.w is -0) << 27 | objType << 28)}: what shade() needs of a 128-B Primitive, in 16 B
-    const float4*        pairs2;     // [nInterior][12] two-level records: pairs[k] followed by the pair records of both children (zeros for a leaf child)
     const float4*        quads;      // [nNodes][8]  layout 1 of the BVH4: four child boxes + four encoded child entries (128 B)
     int32_t nLights, nPrims, nBlas, nTex;
 };
@@ -348,62 +347,6 @@ RT_FORCEINLINE int traverse_bvh2_packed(const DevScene& sc, TRay& r, uint32_t ro
     return steps;
 }
 
-// Two levels per dependent fetch (closest hit).  pairs2[k] = pairs[k] followed by the pair records of k's two children: when the
-// near child is an interior node its own child boxes are already in registers, so the reference's NEXT loop iteration (bvh.cl:28-52:
-// test the near child's children against the unchanged ray->t, sort, prune, push) is evaluated from the same round trip.  Visit
-// order, pushes, `steps` and counters are those of traverse_bvh2_packed - two of its iterations fused - hits are bit-identical.
-// 192 B per event instead of 64: pays only where the kernel is bound by the LENGTH of a ray's dependent fetch chain rather than
-// by fetch throughput, i.e. in the short launches of the late bounces (a few long rays, most of the chip idle).
-RT_FORCEINLINE int traverse_bvh2_packed2(const DevScene& sc, TRay& r, uint32_t rootEntry, uint32_t* stk, WorkCtr& wc)
-{
-    uint32_t cur = rootEntry, sp = 0;
-    int steps = 0;
-    const float tLight = r.t;
-    for (;;) {
-        if (cur & kLeafBit) {
-            const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
-            for (uint32_t i = 0; i < count; i++) { wc.prim++; test_tri_packed(sc, first + i, r); }
-            if (sp == 0) break;
-            cur = STK(--sp);
-            continue;
-        }
-        wc.node++;
-        const float4* p = sc.pairs2 + (size_t)cur * 12;
-        const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-        const float4 b0 = p[4], b1 = p[5], b2 = p[6], b3 = p[7], c0 = p[8], c1 = p[9], c2 = p[10], c3 = p[11];
-        float d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
-        float d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
-        uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
-        const bool swapped = d1 > d2;
-        if (swapped) { float d = d1; d1 = d2; d2 = d; uint32_t e = e1; e1 = e2; e2 = e; }
-        if (d1 >= tLight) {
-            if (sp == 0) break;
-            cur = STK(--sp);
-            continue;
-        }
-        steps++;
-        cur = e1;
-        if (d2 < tLight) { STK(sp) = e2; sp++; steps++; }
-        if (cur & kLeafBit) continue;
-        // second level: the near child's pair record came with the same fetch
-        wc.node++;
-        const float4 n0 = swapped ? c0 : b0, n1 = swapped ? c1 : b1, n2 = swapped ? c2 : b2, n3 = swapped ? c3 : b3;
-        d1 = slab(r, mk4(n0.x, n0.y, n0.z, 0.0f), mk4(n0.w, n1.x, n1.y, 0.0f));
-        d2 = slab(r, mk4(n1.z, n1.w, n2.x, 0.0f), mk4(n2.y, n2.z, n2.w, 0.0f));
-        e1 = __float_as_uint(n3.x); e2 = __float_as_uint(n3.y);
-        if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t e = e1; e1 = e2; e2 = e; }
-        if (d1 >= tLight) {
-            if (sp == 0) break;
-            cur = STK(--sp);
-        } else {
-            steps++;
-            cur = e1;
-            if (d2 < tLight) { STK(sp) = e2; sp++; steps++; }
-        }
-    }
-    return steps;
-}
-
 // BVH4 traversal, bvh.cl:55-96 (children visited in slot order, all four distances taken
 // at node entry).
 template <bool OCC>
@@ -569,12 +512,13 @@ __global__ void k_reset(float4* accum, int32_t first, int32_t n)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) accum[first + i] = splat(0.0f);
 }
-__global__ void k_begin_frame(DevQueues q) // renderer.cpp:66-69
+RT_FORCEINLINE void begin_frame(const DevQueues& q) // renderer.cpp:66-69 (one workgroup)
 {
     if (threadIdx.x == 0) { q.nRays[0] = q.nPix; q.nShadow[0] = 0; }
     if (threadIdx.x < kCursorWords) q.cursor[threadIdx.x] = 0;
     for (int k = threadIdx.x; k < (RT_MAX_BOUNCES + 1) * kTicketClasses; k += blockDim.x) q.shadeTicket[(size_t)k * kTicketStride] = 0;
 }
+__global__ void k_begin_frame(DevQueues q) { begin_frame(q); }   // stage-level API; rt_render folds it into k_generate
 
 // ------------------------------------------------------------------ k_generate
 RT_FORCEINLINE void primary_ray(const RtCamera& cam, int x, int y, int W, int H, int aa, uint32_t& seed, float4& O, float4& D)
@@ -602,9 +546,10 @@ RT_FORCEINLINE void primary_ray(const RtCamera& cam, int x, int y, int W, int H,
         O = ld4(cam.origin);
     }
 }
-__global__ __launch_bounds__(kBlock) void k_generate(DevQueues q, RtCamera cam, int aa)
+__global__ __launch_bounds__(kBlock) void k_generate(DevQueues q, RtCamera cam, int aa, int beginFrame)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (beginFrame && blockIdx.x == 0) begin_frame(q);   // the counters it resets are read by later launches only
     if (threadIdx.x == 0) { q.tile[0][1 + blockIdx.x] = 0ull; if ((blockIdx.x & 63) == 0) { q.super[0][blockIdx.x >> 6] = 0ull; q.supAcc[0][blockIdx.x >> 6] = 0ull; } }   // arm shade(0)'s scan
     if (i >= q.nPix) return;
     const int idx = q.firstPixel + i;
@@ -652,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int
 // all its lanes idle), so the grid always drains.
 // Work distribution: the first chunk of every wave is static (chunk id = global wave id, no atomic, so the
 // launch does not start with thousands of waves hammering one counter); further chunks are dequeued.
-struct PersistTune { int chunk, refill, inner, leafK; int twoLevel; };   // twoLevel: queues up to this length are traced with two tree levels per fetch (0 = never)   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path
+struct PersistTune { int chunk, refill, inner, leafK; };   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path
 
 template <bool OCC>
 __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues q, int b0, int b1, int renderBVH, PersistTune tune)
@@ -697,8 +642,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
             r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
             r.t = tmax; r.prim = -1; r.u = 0.0f; r.v = 0.0f;
             rays = 1; wc.inst = 1;
-            const int st = (!OCC && tune.twoLevel && sc.pairs2 && n <= tune.twoLevel) ? traverse_bvh2_packed2(sc, r, rootEntry, stk, wc)
-                                                                                      : traverse_bvh2_packed<OCC>(sc, r, rootEntry, stk, wc);
+            const int st = traverse_bvh2_packed<OCC>(sc, r, rootEntry, stk, wc);
             if (OCC) { if (st == -1) q.sC[qFirst + idx] = splat(0.0f); }
             else {
                 q.hit[idx] = mk4(r.t, __int_as_float(r.prim), r.u, r.v);

@@ -583,16 +583,59 @@ int TLAS::FindBestMatch(const int* list, int N, int A) const
     }
     return best;
 }
+// World-space bounds of an instance: the reference copies the BLAS root's OBJECT-space box into the TLAS leaf (tlas.cpp:15-17),
+// which is only right for the identity transforms it ever uses (bvh.cpp:53-58; the one writer is commented out, scene.cpp:82).
+// With a real transform the world ray would be slab-tested against the wrong box and the instance culled.  Identity instances
+// keep the reference's copy bit for bit; for any other invT the eight corners of the root box are mapped by inverse(invT) and
+// bounded, padded by a few ulp of the box size (the leaf test must never be tighter than the instance's own root test).
+static bool is_identity(const float* T)
+{
+    static const float I[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+    return memcmp(T, I, sizeof I) == 0 || (T[0] == 1 && T[5] == 1 && T[10] == 1 && T[1] == 0 && T[2] == 0 && T[3] == 0 && T[4] == 0 &&
+                                           T[6] == 0 && T[7] == 0 && T[8] == 0 && T[9] == 0 && T[11] == 0);
+}
+static void instance_world_box(const float* invT, const RtBVHNode2& root, RtFloat4& mn, RtFloat4& mx)
+{
+    // inverse of the affine map p' = A p + t (rows 0-2 of invT; row-major, translation in cells 3/7/11): p = A^-1 (p' - t)
+    const double a[3][3] = { { invT[0], invT[1], invT[2] }, { invT[4], invT[5], invT[6] }, { invT[8], invT[9], invT[10] } };
+    const double t[3] = { invT[3], invT[7], invT[11] };
+    const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                       a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+    if (!(fabs(det) > 1e-30)) throw std::runtime_error("TLAS::Build: an instance transform is singular");
+    double inv[3][3];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
+        const int r1 = (c + 1) % 3, r2 = (c + 2) % 3, c1 = (r + 1) % 3, c2 = (r + 2) % 3;
+        inv[r][c] = (a[r1][c1] * a[r2][c2] - a[r1][c2] * a[r2][c1]) / det;
+    }
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    const float bx[2][3] = { { root.aabbMin.x, root.aabbMin.y, root.aabbMin.z }, { root.aabbMax.x, root.aabbMax.y, root.aabbMax.z } };
+    for (int k = 0; k < 8; k++) {
+        const double p[3] = { bx[k & 1][0] - t[0], bx[(k >> 1) & 1][1] - t[1], bx[(k >> 2) & 1][2] - t[2] };
+        for (int r = 0; r < 3; r++) {
+            const double w = inv[r][0] * p[0] + inv[r][1] * p[1] + inv[r][2] * p[2];
+            lo[r] = std::min(lo[r], w); hi[r] = std::max(hi[r], w);
+        }
+    }
+    float fl[3], fh[3];
+    for (int r = 0; r < 3; r++) {
+        const double pad = 1e-5 * (hi[r] - lo[r]) + 1e-6 * std::max(fabs(lo[r]), fabs(hi[r])) + 1e-30;
+        fl[r] = nextafterf((float)(lo[r] - pad), -INFINITY); fh[r] = nextafterf((float)(hi[r] + pad), INFINITY);
+    }
+    mn = RtFloat4{ fl[0], fl[1], fl[2], 0.0f }; mx = RtFloat4{ fh[0], fh[1], fh[2], 0.0f };
+}
+
 void TLAS::Build()
 {
     int slot[256], live = (int)bvh2_.blasNodes.size();
-    if (live > 256) live = 256; // reference limit: nodeIdx[256], 16-bit child ids
+    // reference limit: nodeIdx[256] and 16-bit child ids (tlas.cpp:11, common.h:111-116); it overruns the array beyond that
+    if (live > 256) throw std::runtime_error("TLAS::Build: " + std::to_string(live) + " BLAS instances, at most 256 are supported");
     if (live == 0) throw std::runtime_error("TLAS::Build: the scene has no BLAS (BuildBLAS comes first)");   // the reference reads slot[0] uninitialised here
     nodesUsed_ = 1;
     for (int i = 0; i < live; i++) {
         const RtBVHNode2& root = bvh2_.bvhNodes[bvh2_.blasNodes[i].bvhIdx];
         RtTLASNode& leaf = tlasNodes[nodesUsed_];
-        leaf.aabbMin = root.aabbMin; leaf.aabbMax = root.aabbMax; // object-space box, as the reference does
+        if (is_identity(bvh2_.blasNodes[i].invT)) { leaf.aabbMin = root.aabbMin; leaf.aabbMax = root.aabbMax; }   // tlas.cpp:15-17, bit for bit
+        else instance_world_box(bvh2_.blasNodes[i].invT, root, leaf.aabbMin, leaf.aabbMax);
         leaf.BLASidx = (uint32_t)i; leaf.leftRight = 0;
         slot[i] = (int)nodesUsed_++;
     }

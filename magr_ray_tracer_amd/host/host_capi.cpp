@@ -74,6 +74,22 @@ int rth_build_blas(RthScene* s, int startIdx, float alpha)
 }
 int rth_set_build_threads(RthScene* s, int threads) { if (!s) return -1; s->scene.bvh2->buildThreads = threads < 1 ? 1 : threads; return 0; }
 int rth_build_bvh4(RthScene* s) { GUARD(s->scene.BuildBVH4()) }
+// BVH4::Convert + Collapse (bvh.cpp:695-787) on a caller-provided BVH2 node array with ONE BLAS rooted at node 0: how the tests feed
+// the reference's own hand-built 13-node tree (bvh.cpp:615-674) through the collapse.
+int rth_bvh4_from_nodes(const RtBVHNode2* nodes, int n, RtBVHNode4* out)
+{
+    if (!nodes || !out || n <= 0) { g_herr = "rth_bvh4_from_nodes: bad argument"; return -1; }
+    try {
+        std::vector<RtPrimitive> prims; std::vector<RtBVHInstance> blas(1);
+        memset(&blas[0], 0, sizeof blas[0]);
+        blas[0].bvhIdx = 0;
+        BVH2 b2(prims, blas);
+        b2.bvhNodes.assign(nodes, nodes + n);
+        BVH4 b4(b2);
+        memcpy(out, b4.Nodes().data(), sizeof(RtBVHNode4) * (size_t)n);
+        return 0;
+    } catch (const std::exception& e) { g_herr = e.what(); return -1; }
+}
 int rth_build_tlas(RthScene* s) { GUARD(delete s->tlas; s->tlas = new TLAS(*s->scene.bvh2); s->tlas->Build()) }
 int rth_set_instance_transform(RthScene* s, int blas, const float invT[16])
 {

@@ -1,8 +1,8 @@
 // scene_io.cpp — on-disk formats either side of the path:
 //   * Scene::LoadModel: Wavefront OBJ (+MTL map_Kd names) with the conventions of the reference's loader
 //     (src/scene.cpp:178-243): faces are fan-triangulated, each face's VERTEX list is reversed while its
-//     texcoord list is not, v -> 1-v, material = the diffuse texture's name (a material of that name must
-//     already exist, e.g. from AddTexture) else the default material.
+//     texcoord list is not, v -> 1-v, material = the diffuse texture's name; the MTL's map_Kd images are loaded
+//     into the atlas first (LoadTexture, scene.cpp:192-195), a missing image is an error.
 //   * SavePNG: the float image of rt_postproc / Renderer::SaveFrame as an 8-bit RGB PNG, bytes computed as
 //     SaveImageF does (template/template.cpp:1629-1644): clamp to 1, (uchar)(c*255).
 // Parity note: the reference parses with tinyobjloader 2.0.0 and stb; no reference test pins their output, so
@@ -49,7 +49,17 @@ int Scene::LoadModel(const std::string& filename, const std::string& defaultMat,
         std::string tag; ls >> tag;
         if (tag == "v") { float3 p; ls >> p.x >> p.y >> p.z; V.push_back(p); }
         else if (tag == "vt") { float2 t; ls >> t.x >> t.y; VT.push_back(t); }
-        else if (tag == "mtllib") { std::string m; ls >> m; parseMtl(dirOf(filename) + m, kdOf); }
+        else if (tag == "mtllib") {
+            std::string m; ls >> m; parseMtl(dirOf(filename) + m, kdOf);
+            // scene.cpp:192-195: every MTL material with a diffuse texture gets its image loaded (material name = texture name)
+            // before any face is added.  A texture registered already (AddTexture / an earlier LoadTexture) is kept.
+            if (!forceDefaultMat)
+                for (const auto& kv : kdOf)
+                    if (!kv.second.empty() && !HasMaterial(kv.second)) {
+                        try { LoadTexture(dirOf(filename) + kv.second, kv.second); }
+                        catch (const std::exception& e) { throw std::runtime_error("LoadModel: " + filename + ": material '" + kv.first + "': " + e.what()); }
+                    }
+        }
         else if (tag == "usemtl") { ls >> curMtl; }
         else if (tag == "f") {
             std::vector<float3> fv; std::vector<float2> ft;

@@ -41,6 +41,11 @@ for shading in SHADING_NEE SHADING_SIMPLE; do
   done
  done
 done
+# post-processing chain (src/cl/postproc.cl: prep, vignetting, gammaCorr, chromatic are buffer kernels; display / saveImage need a GL image)
+if [[ $FORCE -eq 1 || ! -s "$OUT/postproc.co" ]]; then
+  "$CLANG" -x cl -cl-std=CL2.0 -target amdgcn-amd-amdhsa -mcpu=gfx950 -I "$REF" \
+      -O2 -ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt -w src/cl/postproc.cl -o "$OUT/postproc.co"
+fi
 # the runner that loads these code objects (own code, oracle/ref_runner.cpp)
 if [[ $FORCE -eq 1 || ! -s "$OUT/libref_runner.so" || "$HERE/ref_runner.cpp" -nt "$OUT/libref_runner.so" ]]; then
   /opt/rocm/bin/hipcc -O2 -fPIC -shared -x c++ "$HERE/ref_runner.cpp" -o "$OUT/libref_runner.so" -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -L/opt/rocm/lib -lamdhip64

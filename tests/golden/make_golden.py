@@ -126,6 +126,22 @@ def make_frame(name, outdir):
           os.path.getsize(path) // 1024, "KiB", flush=True)
 
 
+def make_post(outdir):
+    """refpost.npz: the reference's postproc.cl kernels (prep -> [vignetting] -> [gammaCorr] -> [chromatic], renderer.cpp:95-124)
+    on the deterministic accumulator band of helpers.post_test_accum, one output per parameter set of helpers.POST_SETS."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import POST_SETS, post_test_accum
+    from ref_gpu import RefPost
+    rows = 4
+    band = post_test_accum(rows)
+    rp = RefPost()
+    outs = {f"out{k}": rp.run(band, *ps)[:, :3].copy() for k, ps in enumerate(POST_SETS)}
+    rp.close()
+    path = os.path.join(outdir, "refpost.npz")
+    np.savez_compressed(path, rows=np.int32(rows), params=np.array(POST_SETS, np.float64), **outs)
+    print("post ->", path, os.path.getsize(path) // 1024, "KiB", flush=True)
+
+
 if __name__ == "__main__":
     out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "golden")
     os.makedirs(out, exist_ok=True)
@@ -136,3 +152,5 @@ if __name__ == "__main__":
     for name in FRAME_CASES:
         if not only or name in only or "frames" in only:
             make_frame(name, out)
+    if not only or "post" in only:
+        make_post(out)

@@ -278,3 +278,20 @@ def load_frame_fixture(path):
                seed0=g["seed0"].tolist(), shadow=shadow, accum=g["accum"], first_pixel=y0 * Wd)
     bc = dict(zip(g["branch_names"].tolist(), g["branch_counts"].tolist()))
     return sa, v, cam, (Wd, Hd, y0, y1), cap, g["heat"], bc
+
+
+# ---- post-processing fixtures ------------------------------------------------------------------------------------------------
+POST_SETS = [(1, 0.0, 1.0, 0.0), (4, 0.6, 1.0, 0.02), (4, 0.0, 0.9, 0.0), (3, 0.35, 0.9, 0.015), (2, 1.0, 2.2, 0.25)]
+
+
+def post_test_accum(rows):
+    """A deterministic accumulator band with values on both sides of the clamp and exact zeros."""
+    i = np.arange(rows * REF_W, dtype=np.float64)
+    a = np.zeros((rows * REF_W, 4), np.float32)
+    a[:, 0] = (np.abs(np.sin(i * 0.0137)) * 5.0).astype(np.float32)
+    a[:, 1] = ((i % 977) / 977.0 * 3.5).astype(np.float32)
+    a[:, 2] = (np.abs(np.cos(i * 0.0031)) ** 3 * 1.7).astype(np.float32)
+    a[::13, :3] = 0
+    return a
+
+

@@ -201,3 +201,66 @@ class RefGPU:
             self.R.ref_free(p)
         self._bufs = []
         self.R.ref_unload(self.mod)
+
+
+class RefPost:
+    """The reference's post-processing kernels (src/cl/postproc.cl compiled unmodified into oracle/_ref/postproc.co): prep ->
+    [vignetting] -> [gammaCorr] -> [chromatic] over two swap buffers, in the order and under the conditions of Renderer::PostProc
+    (src/renderer.cpp:95-124).  The kernels take the pixel from get_global_id at the compile-time 1280x720, so they are launched
+    over the first `rows` rows.  `display` / `saveImage` go through a GL image and are not run; what is returned is the swap
+    buffer `display` would show (float3 with 16-byte stride)."""
+
+    def __init__(self):
+        self.R = C.CDLL(os.path.join(REF_DIR, "libref_runner.so"))
+        self.R.ref_last_error.restype = C.c_char_p
+        self._chk(self.R.ref_init(0))
+        self.mod = C.c_void_p()
+        self._chk(self.R.ref_load(os.path.join(REF_DIR, "postproc.co").encode(), C.byref(self.mod)))
+
+    _chk = RefGPU._chk
+
+    def run(self, accum_rows, frames, vignette, gamma, chromatic):
+        a = np.ascontiguousarray(accum_rows, dtype=np.float32).reshape(-1, 4)
+        n = len(a)
+        assert n % 256 == 0
+        bufs = []
+
+        def dbuf(arr=None, nbytes=None):
+            p = C.c_void_p()
+            nb = arr.nbytes if arr is not None else nbytes
+            self._chk(self.R.ref_malloc(C.byref(p), C.c_size_t(nb)))
+            if arr is not None:
+                self._chk(self.R.ref_h2d(p, arr.ctypes.data_as(C.c_void_p), C.c_size_t(nb)))
+            bufs.append(p)
+            return p
+
+        def launch(name, args):
+            hold = [x if isinstance(x, np.ndarray) else C.c_void_p(x.value) for x in args]
+            arr = (C.c_void_p * len(args))(*[h.ctypes.data_as(C.c_void_p) if isinstance(h, np.ndarray) else C.cast(C.pointer(h), C.c_void_p) for h in hold])
+            self._chk(self.R.ref_launch(self.mod, name.encode(), n, 256, arr))
+
+        st = np.zeros(1, dtype=W.Settings)
+        st["frames"] = frames
+        d_acc, src, dst, d_set = dbuf(a), dbuf(nbytes=16 * n), dbuf(nbytes=16 * n), dbuf(st)
+        launch("prep", [d_acc, src, d_set])                                   # renderer.cpp:101-102
+        if vignette > 0:                                                      # :103-108
+            launch("vignetting", [src, dst, np.array([vignette], np.float32)])
+            src, dst = dst, src
+        if gamma != 1:                                                        # :109-114
+            launch("gammaCorr", [src, dst, np.array([gamma], np.float32)])
+            src, dst = dst, src
+        if chromatic > 0:                                                     # :115-120
+            launch("chromatic", [src, dst, np.array([chromatic], np.float32)])
+            src, dst = dst, src
+        out = np.zeros((n, 4), np.float32)
+        self._chk(self.R.ref_d2h(out.ctypes.data_as(C.c_void_p), src, C.c_size_t(out.nbytes)))
+        for p in bufs:
+            self.R.ref_free(p)
+        return out
+
+    def close(self):
+        self.R.ref_unload(self.mod)
+
+
+def post_available():
+    return os.path.exists(os.path.join(REF_DIR, "libref_runner.so")) and os.path.exists(os.path.join(REF_DIR, "postproc.co"))

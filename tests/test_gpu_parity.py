@@ -953,3 +953,42 @@ def test_upload_rejects_tlas_cycles_and_overdeep_tlas():
         d.upload(deep)
     d.upload(sa)           # the context is still usable
     d.close()
+
+
+def test_obj_mtl_png_model_renders_textured(tmp_path):
+    """LoadModel("m.obj", "white") with an MTL that names a PNG: the file-loaded texture is what the hit primitives are shaded with
+    (HIP vs oracle bit for bit, and the image differs from the same model forced to the default material)."""
+    from test_io_postproc_cpu import write_textured_obj
+    from magr_ray_tracer_amd.scene import Scene, material
+    write_textured_obj(tmp_path)
+
+    def build(force):
+        s = Scene()
+        s.AddMaterial("white", material(color=(.8, .8, .8)))
+        s.AddMaterial("lamp", material(color=(1, 1, 1), light=True, emittance=(30, 30, 30)))
+        s.LoadModel(tmp_path / "m.obj", "white", forceDefaultMat=force)
+        s.AddQuad((-1, -1, 2.5), (2, -1, 2.5), (2, 2, 2.5), (-1, 2, 2.5), "lamp")     # faces -z, towards the quad
+        s.BuildBLAS(0, 1.0)
+        return s.arrays()
+    Wd, Hd = 96, 54
+    view = dict(origin=(0.5, 0.5, -1.6), forward=(0, 0, -1), fov=60.0, aperture=0.0)
+    cam = scenes.camera_for(view, Wd, Hd)
+    imgs = []
+    for force in (False, True):
+        sa = build(force)
+        o = Oracle(sa, Wd, Hd, **DEFAULT)
+        d = Device(Wd, Hd, **DEFAULT)
+        d.upload(sa)
+        ref, seeds, e, c = o.render(cam, 3)
+        d.seed_default()
+        d.render(cam, 3)
+        got = d.read_accum()
+        assert_bits(got, ref, "OBJ+MTL+PNG scene")
+        imgs.append(got)
+        if not force:   # primary rays do land on the textured triangles
+            rays = o.generate(cam, 0, Wd * Hd, seed_stream(0, Wd * Hd))
+            o.extend(rays)
+            hit = rays["primIdx"][rays["primIdx"] >= 0]
+            assert (sa.mats["texIdx"][sa.prims["matIdx"][hit]] != -1).sum() > 200
+        d.close()
+    assert np.abs(imgs[0] - imgs[1]).max() > 0.05

@@ -218,3 +218,37 @@ def test_extend_every_bounce_hip_vs_reference_kernel_bit_exact(accel):
     assert total > 30000 and sum(int((e["inside"] != 0).sum()) for e in cap["ext"]) > 1000
     d.close()
     ref.close()
+
+
+from helpers import POST_SETS, post_test_accum  # noqa: E402
+
+
+@pytest.mark.skipif(not ref_gpu.post_available(), reason="oracle/_ref/postproc.co not built")
+@pytest.mark.parametrize("frames,vignette,gamma,chromatic", POST_SETS)
+def test_postproc_chain_vs_reference_kernels(frames, vignette, gamma, chromatic):
+    """Renderer::PostProc's chain through the reference's own postproc.cl kernels (prep, vignetting, gammaCorr, chromatic;
+    renderer.cpp:95-124) against k_postproc and the oracle.  Without gamma everything is + - * / fma: bit for bit.  gammaCorr is
+    pow(): the HIP kernel calls the same ROCm device-library pow as the reference's kernel (bit for bit), the CPU oracle uses
+    glibc's powf (<= 2 ulp)."""
+    from oracle.oracle_py import postproc as orc_postproc
+    rows = 16
+    band = post_test_accum(rows)
+    rp = ref_gpu.RefPost()
+    ref = rp.run(band, frames, vignette, gamma, chromatic)
+    rp.close()
+    full = np.zeros((RH, RW, 4), np.float32)
+    full.reshape(-1, 4)[:rows * RW] = band
+    d = Device(RW, RH, **DEFAULT)
+    d.write_accum(full)
+    f, b8 = d.postproc(frames, vignette, gamma, chromatic)
+    d.close()
+    got = f.reshape(-1, 4)[:rows * RW]
+    assert_bits(np.minimum(ref[:, :3], 1.0), got[:, :3], "k_postproc vs the reference's postproc kernels")
+    of, ob8 = orc_postproc(full, frames, vignette, gamma, chromatic)
+    o = of.reshape(-1, 4)[:rows * RW]
+    if gamma == 1.0:
+        assert_bits(o[:, :3], np.minimum(ref[:, :3], 1.0), "oracle postproc vs the reference's kernels")
+    else:
+        assert max_rel(o[:, :3], np.minimum(ref[:, :3], 1.0), 1e-6) < 3e-7
+    # the 8-bit image SaveFrame writes: (uchar)(min(c, 1) * 255) of the same floats
+    assert np.array_equal(b8.reshape(-1, 4)[:rows * RW, :3], (np.minimum(ref[:, :3], 1.0) * np.float32(255)).astype(np.uint8))

@@ -118,6 +118,49 @@ def test_obj_loader_conventions(tmp_path):
     assert np.allclose(p["N"][0][:3], [0, 0, -1])
 
 
+def write_textured_obj(tmp_path):
+    """A 2 x 1.5 quad with texcoords + a plain triangle, an MTL whose `textured` material names tex.png, and that 4x3 RGB PNG."""
+    (tmp_path / "m.obj").write_text(OBJ.replace("m.mtl", "t.mtl"))
+    (tmp_path / "t.mtl").write_text("newmtl textured\nKd 1 1 1\nmap_Kd tex.png\nnewmtl plain\nKd 1 0 0\n")
+    pix = (np.arange(4 * 3 * 3).reshape(3, 4, 3) * 7 % 256).astype(np.uint8)
+    (tmp_path / "tex.png").write_bytes(_png_bytes(pix, 2))
+    return pix
+
+
+def test_load_model_loads_the_mtl_textures(tmp_path):
+    """Scene::LoadModel (scene.cpp:190-195): every MTL material with a diffuse texture has its image loaded into the atlas and a
+    material named after the texture added BEFORE the faces, so a bare LoadModel("x.obj", "white") renders textured."""
+    pix = write_textured_obj(tmp_path)
+    s = Scene()
+    s.AddMaterial("white", material(color=(.8, .8, .8)))
+    n = s.LoadModel(tmp_path / "m.obj", "white")
+    assert n == 3
+    s.BuildBLAS(0, 1.0)
+    sa = s.arrays()
+    m = sa.mats[sa.prims["matIdx"][0]]
+    assert (int(m["texIdx"]), int(m["texW"]), int(m["texH"])) == (0, 4, 3) and not m["isDielectric"]
+    assert sa.prims["matIdx"][0] == sa.prims["matIdx"][1] != sa.prims["matIdx"][2]
+    assert sa.mats[sa.prims["matIdx"][2]]["texIdx"] == -1                      # `plain` has no map_Kd: the default material
+    assert len(sa.tex) == 12 and np.array_equal(sa.tex[:, :3], _stb_float(pix).reshape(-1, 3))
+    # loading the same model again reuses the registered texture instead of growing the atlas
+    s2 = Scene()
+    s2.AddMaterial("white", material(color=(.8, .8, .8)))
+    s2.LoadModel(tmp_path / "m.obj", "white")
+    s2.LoadModel(tmp_path / "m.obj", "white", pos=(3, 0, 0))
+    assert len(s2.texture_array()) == 12
+    # forceDefaultMat: no texture is loaded or used
+    s3 = Scene()
+    s3.AddMaterial("white", material(color=(.8, .8, .8)))
+    s3.LoadModel(tmp_path / "m.obj", "white", forceDefaultMat=True)
+    assert len(s3.texture_array()) == 0
+    # a missing image is reported, not silently rendered untextured
+    (tmp_path / "tex.png").unlink()
+    s4 = Scene()
+    s4.AddMaterial("white", material(color=(.8, .8, .8)))
+    with pytest.raises(RuntimeError, match="tex.png"):
+        s4.LoadModel(tmp_path / "m.obj", "white")
+
+
 def test_gltf_reader_applies_node_transforms(tmp_path):
     import json
     from magr_ray_tracer_amd import gltf

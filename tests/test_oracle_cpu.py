@@ -398,3 +398,137 @@ def test_oracle_follows_reference_frames_launch_by_launch(path):
     steps, _ = o.extend(rays, want_steps=True)
     assert_bits(steps.astype(np.float32) / np.float32(255.0), heat, "steps / 255 of the primary rays")
     assert stats["rays"] > 3000
+
+
+def test_oracle_postproc_matches_reference_postproc_kernels():
+    """tests/golden/refpost.npz: outputs of the reference's own postproc.cl kernels (compiled for gfx950, run on the MI355X by
+    tests/golden/make_golden.py) for the parameter sets of helpers.POST_SETS.  Without gamma the chain is + - * / fma: bit for
+    bit; gammaCorr is pow(): glibc's powf against the ROCm device library's, <= 2 ulp."""
+    from helpers import POST_SETS, REF_H, REF_W, post_test_accum
+    path = os.path.join(ROOT, "tests", "golden", "refpost.npz")
+    if not os.path.exists(path):
+        pytest.skip("refpost.npz not generated yet")
+    g = np.load(path)
+    rows = int(g["rows"])
+    assert np.array_equal(g["params"], np.array(POST_SETS, np.float64))
+    full = np.zeros((REF_H, REF_W, 4), np.float32)
+    full.reshape(-1, 4)[:rows * REF_W] = post_test_accum(rows)
+    for k, (frames, vignette, gamma, chromatic) in enumerate(POST_SETS):
+        f, b8 = oracle_py.postproc(full, frames, vignette, gamma, chromatic)
+        o = f.reshape(-1, 4)[:rows * REF_W, :3]
+        ref = np.minimum(g[f"out{k}"], np.float32(1.0))
+        if gamma == 1.0:
+            assert_bits(o, ref, f"postproc set {k}")
+        else:
+            assert max_rel(o, ref, 1e-6) < 3e-7, k
+
+
+def _instanced_pair(moved):
+    """Two boxes on a floor.  moved=True: box 2 is modelled around the origin and placed by its instance transform (invT = world ->
+    instance); moved=False: the same box with its vertices pre-transformed into world space, identity instance."""
+    from magr_ray_tracer_amd.scenes import Scene, _std_materials, box_tris
+    a = np.deg2rad(31.0)
+    T = np.array([[np.cos(a), 0, -np.sin(a), 1.6], [0, 1, 0, 0.25], [np.sin(a), 0, np.cos(a), -0.4], [0, 0, 0, 1]], np.float64)   # instance -> world
+    s = Scene()
+    _std_materials(s)
+    s.AddTriangles(box_tris((-2.4, 0, -0.8), (-0.9, 1.4, 0.6)), "red")
+    s.AddQuad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6), "grey")
+    s.AddQuad((-1, 4, -1), (1, 4, -1), (1, 4, 1), (-1, 4, 1), "white-light")
+    s.BuildBLAS(0, 1.0)
+    st = s.num_prims
+    tris = box_tris((-0.7, 0.0, -0.5), (0.7, 1.6, 0.5)).astype(np.float64)
+    if not moved:
+        tris = (tris.reshape(-1, 3) @ T[:3, :3].T + T[:3, 3]).reshape(-1, 3, 3)
+    s.AddTriangles(tris.astype(np.float32), "green")
+    s.BuildBLAS(st, 1.0)
+    if moved:
+        s.SetInstanceTransform(1, np.linalg.inv(T).astype(np.float32))
+    return s.arrays(), T
+
+
+def test_tlas_leaf_bounds_follow_the_instance_transform():
+    """The reference copies the BLAS root's object-space box into the TLAS leaf (tlas.cpp:15-17): right for its identity instances
+    only.  A moved instance must get the world-space bounds of its box, or the world ray is slab-tested against the wrong box and
+    the instance is culled: the moved instance has to render like the same geometry pre-transformed into world space."""
+    sa_m, T = _instanced_pair(True)
+    sa_w, _ = _instanced_pair(False)
+    # identity instance 0: the reference's copy, bit for bit
+    leaves = {int(n["BLASidx"]): n for n in sa_m.tlas[1:] if n["leftRight"] == 0}
+    root0 = sa_m.bvh2[sa_m.blas["bvhIdx"][0]]
+    assert_bits(leaves[0]["aabbMin"], root0["aabbMin"], "identity leaf min")
+    assert_bits(leaves[0]["aabbMax"], root0["aabbMax"], "identity leaf max")
+    # moved instance 1: the leaf contains every world-space vertex and is not much larger than their bounds
+    world = sa_w.prims["v0"][-12:, :3].tolist() + sa_w.prims["v1"][-12:, :3].tolist() + sa_w.prims["v2"][-12:, :3].tolist()
+    world = np.array(world)
+    lo, hi = leaves[1]["aabbMin"][:3], leaves[1]["aabbMax"][:3]
+    assert (world >= lo - 1e-6).all() and (world <= hi + 1e-6).all()
+    assert np.all(lo > world.min(0) - 1e-3) and np.all(hi < world.max(0) + 1e-3)
+    # and the two scenes look the same to the primary rays
+    Wd, Hd = 160, 90
+    view = dict(origin=(0.4, 2.2, 5.5), forward=(0.05, 0.2, 0.97), fov=65.0, aperture=0.0)
+    cam = scenes.camera_for(view, Wd, Hd)
+    hits = []
+    for sa in (sa_m, sa_w):
+        o = Oracle(sa, Wd, Hd, **DEFAULT)
+        seeds = seed_stream(0, Wd * Hd)
+        rays = o.generate(cam, 0, Wd * Hd, seeds)
+        o.extend(rays)
+        hits.append(rays)
+    a, b = hits
+    on_box = (b["primIdx"] >= len(sa_w.prims) - 12)
+    assert on_box.sum() > 300                                  # the moved box is in view ...
+    same = a["primIdx"] == b["primIdx"]
+    assert same.mean() > 0.998 and (a["primIdx"][on_box] == b["primIdx"][on_box]).mean() > 0.98   # ... and is hit (edges may flip)
+    assert max_rel(a["t"][same & on_box], b["t"][same & on_box], 1e-3) < 1e-4
+
+
+def test_tlas_refuses_more_than_256_instances():
+    from magr_ray_tracer_amd.scenes import Scene, _std_materials
+    s = Scene()
+    _std_materials(s)
+    for k in range(257):
+        st = s.num_prims
+        s.AddTriangle((k, 0, 0), (k + 0.5, 0, 0), (k, 0.5, 0), "red")
+        s.BuildBLAS(st, 1.0)
+    with pytest.raises(RuntimeError, match="256"):
+        s.arrays(bvh4=False)
+
+
+def test_bvh4_collapse_of_the_reference_13_node_fixture():
+    """The one builder fixture the reference holds: the hand-built 13-node BVH2 of src/bvh.cpp:615-674 (disabled `#if 0` debugging
+    input of BVH4::BVH4, no expected output recorded).  The collapse BVH4::Convert / Collapse (bvh.cpp:695-787) prescribes for it,
+    worked out by hand:
+
+        BVH2:  0 -> (1, 2)   1 -> (3, leaf4)   2 -> (leaf5, 6)   3 -> (leaf7, leaf8)   6 -> (9, leaf10)   9 -> (leaf11, leaf12)
+               boxes +-20, +-9, +-12, +-8, +-10, +-9 for nodes 0, 1, 2, 3, 6, 9; leaf k has count = first = k (leaf 12: first 0)
+        Convert: every interior node gets its two children in slots 0, 1 (leaf: its first/count, interior: node id / 0).
+        Collapse(0): slots (1, 2), both adoptable; half areas 3*18^2 = 972 and 3*24^2 = 1728 -> adopt node 2: (1, leaf5, 6);
+                     candidates 1 (972) and 6 (3*20^2 = 1200) -> adopt node 6: (1, leaf5, 9, leaf10); full -> stop.
+        Collapse(1): (3, leaf4) -> adopt node 3: (leaf7, leaf4, leaf8).   Collapse(9): two leaves, nothing to adopt.
+        Nodes 2, 3 and 6 are absorbed but stay in the array as Convert left them (the array keeps the BVH2's index space).
+
+    This pins the restatement's collapse rule (greedy largest-area adoption, slot placement, recursion order); the builders'
+    node-array parity with the reference's own bvh.cpp output stays UNPINNED - building that file needs stand-in headers."""
+    n2 = np.zeros(13, dtype=W.BVHNode2)
+
+    def interior(i, first, half):
+        n2["aabbMin"][i][:3], n2["aabbMax"][i][:3] = -half, half
+        n2["first"][i], n2["count"][i] = first, 0
+    interior(0, 1, 20), interior(1, 3, 9), interior(2, 5, 12), interior(3, 7, 8), interior(6, 9, 10), interior(9, 11, 9)
+    for k in (4, 5, 7, 8, 10, 11):
+        n2["first"][k], n2["count"][k] = k, k
+    n2["first"][12], n2["count"][12] = 0, 12           # the fixture sets `count` twice and never `first`
+    out = np.zeros(13, dtype=W.BVHNode4)
+    assert W.host_lib().rth_bvh4_from_nodes(W.ptr(n2), 13, W.ptr(out)) == 0
+    INV = -1
+    assert out["first"][0].tolist() == [1, 5, 9, 10] and out["count"][0].tolist() == [0, 5, 0, 10]
+    assert out["first"][1].tolist() == [7, 4, 8, INV] and out["count"][1].tolist() == [7, 4, 8, INV]
+    assert out["first"][9].tolist() == [11, 0, INV, INV] and out["count"][9].tolist() == [11, 12, INV, INV]
+    # child boxes travel with the adopted children
+    assert out["aabbMax"][0][0][:3].tolist() == [9, 9, 9] and out["aabbMax"][0][2][:3].tolist() == [9, 9, 9]
+    assert out["aabbMax"][0][1][:3].tolist() == [0, 0, 0] and out["aabbMin"][0][2][:3].tolist() == [-9, -9, -9]
+    # absorbed nodes keep their Convert() state; leaf slots of the array stay zero-filled
+    assert out["first"][2].tolist() == [5, 6, INV, INV] and out["count"][2].tolist() == [5, 0, INV, INV]
+    assert out["first"][3].tolist() == [7, 8, INV, INV] and out["first"][6].tolist() == [9, 10, INV, INV] and out["count"][6].tolist() == [0, 10, INV, INV]
+    for k in (4, 5, 7, 8, 10, 11, 12):
+        assert not out[k].tobytes().strip(b"\0")
