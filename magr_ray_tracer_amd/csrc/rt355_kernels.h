@@ -1392,8 +1392,15 @@ RT_FORCEINLINE float3 post_chain(const float4* accum, int idx, const PostParams&
     if (pp.vignette > 0) { // postproc.cl:18-32
         const int x = idx % pp.width, y = idx / pp.width;
         const float px = (float)x / (float)pp.width - 0.5f, py = (float)y / (float)pp.height - 0.5f;
-        float d = __fmaf_rn(py, py, px * px);                                    // length(float2): dot then sqrt (library rescaling
-        float len = d < 1.17549435e-38f ? sqrtf(__fmaf_rn(py * 0x1p+86f, py * 0x1p+86f, (px * 0x1p+86f) * (px * 0x1p+86f))) * 0x1p-86f : sqrtf(d); // branch for tiny)
+        // length(float2) as ROCm's OpenCL library computes it for the reference's kernel (read from its gfx950 code object):
+        // fma(y, y, x*x), rescaled by 2^+-n when tiny / infinite, and the HARDWARE square root v_sqrt_f32 (1 ulp, not the correctly
+        // rounded one).  Post-processing is compared with the reference's own postproc kernels bit for bit (tests/test_gpu_reference.py),
+        // so k_postproc issues the same instruction; the CPU oracle has no such instruction and is held to 2 ulp on vignetted images.
+        float d = __fmaf_rn(py, py, px * px);
+        float len;
+        if (d < 1.17549435e-38f) { const float sx = px * 0x1p+86f, sy = py * 0x1p+86f; len = __builtin_amdgcn_sqrtf(__fmaf_rn(sy, sy, sx * sx)) * 0x1p-86f; }
+        else if (d == INFINITY) { const float sx = px * 0x1p-65f, sy = py * 0x1p-65f; len = __builtin_amdgcn_sqrtf(__fmaf_rn(sy, sy, sx * sx)) * 0x1p+65f; }
+        else len = __builtin_amdgcn_sqrtf(d);
         float t = fminf(fmaxf(len, 0.0f), 1.0f);                                 // smoothstep(0,1,len) = t*t*fma(t,-2,3)
         float vig = 1 - (t * t) * __fmaf_rn(t, -2.0f, 3.0f);
         c = make_float3(__fmaf_rn(c.x * vig - c.x, pp.vignette, c.x), __fmaf_rn(c.y * vig - c.y, pp.vignette, c.y),

@@ -337,12 +337,16 @@ def test_postproc_chain_matches_oracle():
     d.seed_default()
     d.render(cam, 3)
     acc = d.read_accum()
-    # no gamma: only + - * / sqrt fma -> bit-exact, float image and bytes
+    # prep + chromatic: only + - * / fma -> bit-exact, float image and bytes.  vignetting goes through length(), which the reference's
+    # kernel (and k_postproc, to match it bit for bit: test_postproc_chain_vs_reference_kernels) evaluates with the hardware v_sqrt_f32
     for vig, chroma in ((0.0, 0.0), (0.7, 0.0), (0.0, 0.15), (0.5, 0.05)):
         f, b = d.postproc(3, vignette=vig, gamma=1.0, chromatic=chroma)
         ef, eb = postproc(acc, 3, vig, 1.0, chroma)
-        assert_bits(f, ef, f"postproc float vig={vig} chroma={chroma}")
-        assert np.array_equal(b, eb)
+        if vig == 0.0:
+            assert_bits(f, ef, f"postproc float vig={vig} chroma={chroma}")
+            assert np.array_equal(b, eb)
+        else:
+            assert max_rel(f, ef, 1e-6) < 3e-6 and np.abs(b.astype(int) - eb.astype(int)).max() <= 1
     # default gamma 0.9 goes through pow(): tolerance on floats, bytes may differ by one code
     f, b = d.postproc(3, vignette=0.3, gamma=0.9, chromatic=0.05)
     ef, eb = postproc(acc, 3, 0.3, 0.9, 0.05)

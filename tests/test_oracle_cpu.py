@@ -402,8 +402,8 @@ def test_oracle_follows_reference_frames_launch_by_launch(path):
 
 def test_oracle_postproc_matches_reference_postproc_kernels():
     """tests/golden/refpost.npz: outputs of the reference's own postproc.cl kernels (compiled for gfx950, run on the MI355X by
-    tests/golden/make_golden.py) for the parameter sets of helpers.POST_SETS.  Without gamma the chain is + - * / fma: bit for
-    bit; gammaCorr is pow(): glibc's powf against the ROCm device library's, <= 2 ulp."""
+    tests/golden/make_golden.py) for the parameter sets of helpers.POST_SETS.  prep and chromatic are + - * / fma: bit for bit;
+    vignetting goes through length() = the hardware v_sqrt_f32 and gammaCorr through the device library's pow(): a few ulp."""
     from helpers import POST_SETS, REF_H, REF_W, post_test_accum
     path = os.path.join(ROOT, "tests", "golden", "refpost.npz")
     if not os.path.exists(path):
@@ -417,10 +417,10 @@ def test_oracle_postproc_matches_reference_postproc_kernels():
         f, b8 = oracle_py.postproc(full, frames, vignette, gamma, chromatic)
         o = f.reshape(-1, 4)[:rows * REF_W, :3]
         ref = np.minimum(g[f"out{k}"], np.float32(1.0))
-        if gamma == 1.0:
+        if gamma == 1.0 and vignette == 0.0:
             assert_bits(o, ref, f"postproc set {k}")
-        else:
-            assert max_rel(o, ref, 1e-6) < 3e-7, k
+        else:   # pow() and the hardware sqrt inside length() (vignetting) have no bit-exact CPU counterpart
+            assert max_rel(o, ref, 1e-6) < 3e-6, k
 
 
 def _instanced_pair(moved):
