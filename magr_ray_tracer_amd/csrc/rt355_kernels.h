@@ -124,6 +124,130 @@ RT_FORCEINLINE float4 normalize4(float4 v)
     return muls(v, r);
 }
 
+// ------------------------------------------------------------------ transcendentals
+// exp (Beer's law, glass.cl:4-9), sin / cos (fisheye camera, sphere-light sampling), acos / atan2 (sphere texture lookup).  The
+// device library's versions lean on hardware approximations (v_exp_f32, v_sin_f32 ...) that no CPU reproduces, and one last-bit
+// difference in a Fresnel draw or a texel index flips a whole path; so this path and the CPU oracle both evaluate the single-precision
+// Cephes algorithms (S. Moshier: expf.c, sinf.c, asinf.c, atanf.c) as plain sequences of IEEE + - * / sqrt - transcribed separately
+// here and in oracle/oracle.c - and agree bit for bit on every scene.  They are within 2 ulp of the correctly rounded value, i.e. as
+// close to the reference's builtins as those are to each other.
+RT_FORCEINLINE float rt_expf(float x)
+{
+    if (x != x) return x;
+    if (x > 88.7228394f) return INFINITY;
+    if (x < -103.972076f) return 0.0f;
+    const float n = floorf(x * 1.44269504088896341f + 0.5f);
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    const float z = r * r;
+    float p = 1.9875691500E-4f;
+    p = p * r + 1.3981999507E-3f;
+    p = p * r + 8.3334519073E-3f;
+    p = p * r + 4.1665795894E-2f;
+    p = p * r + 1.6666665459E-1f;
+    p = p * r + 5.0000001201E-1f;
+    float e = p * z;
+    e = e + r;
+    e = e + 1.0f;
+    int k = (int)n;
+    if (k > 127) { e = e * 0x1p127f; k -= 127; }
+    else if (k < -126) { e = e * 0x1p-126f; k += 126; }
+    return e * __uint_as_float((uint32_t)(k + 127) << 23);
+}
+RT_FORCEINLINE float rt_trig_reduce(float ax, int& j)   // octant (made even-up) and remainder in [-pi/4, pi/4], three-term Cody-Waite
+{
+    j = (int)(1.27323954473516f * ax);
+    float y = (float)j;
+    if (j & 1) { j += 1; y = y + 1.0f; }
+    j &= 7;
+    float r = ax - y * 0.78515625f;
+    r = r - y * 2.4187564849853515625e-4f;
+    r = r - y * 3.77489497744594108e-8f;
+    return r;
+}
+RT_FORCEINLINE float rt_sin_kernel(float x, float z) { float p = -1.9515295891E-4f * z + 8.3321608736E-3f; p = p * z - 1.6666654611E-1f; p = p * z; p = p * x; return p + x; }
+RT_FORCEINLINE float rt_cos_kernel(float z) { float p = 2.443315711809948E-005f * z - 1.388731625493765E-003f; p = p * z + 4.166664568298827E-002f; p = p * z; p = p * z; p = p - 0.5f * z; return p + 1.0f; }
+RT_FORCEINLINE float rt_sinf(float x)
+{
+    if (x != x) return x;
+    bool neg = x < 0.0f;
+    const float ax = neg ? -x : x;
+    if (ax > 8192.0f) return 0.0f;
+    int j; const float r = rt_trig_reduce(ax, j);
+    if (j > 3) { neg = !neg; j -= 4; }
+    const float z = r * r;
+    const float y = (j == 1 || j == 2) ? rt_cos_kernel(z) : rt_sin_kernel(r, z);
+    return neg ? -y : y;
+}
+RT_FORCEINLINE float rt_cosf(float x)
+{
+    if (x != x) return x;
+    const float ax = x < 0.0f ? -x : x;
+    if (ax > 8192.0f) return 0.0f;
+    int j; const float r = rt_trig_reduce(ax, j);
+    bool neg = false;
+    if (j > 3) { neg = !neg; j -= 4; }
+    if (j > 1) neg = !neg;
+    const float z = r * r;
+    const float y = (j == 1 || j == 2) ? rt_sin_kernel(r, z) : rt_cos_kernel(z);
+    return neg ? -y : y;
+}
+RT_FORCEINLINE float rt_asinf(float x)
+{
+    const bool neg = x < 0.0f;
+    const float a = neg ? -x : x;
+    if (a > 1.0f) return (x - x) / (x - x);
+    if (a < 1.0e-4f) return x;
+    float z, w; bool flag = false;
+    if (a > 0.5f) { z = 0.5f * (1.0f - a); w = sqrtf(z); flag = true; }
+    else { w = a; z = w * w; }
+    float p = 4.2163199048E-2f * z + 2.4181311049E-2f;
+    p = p * z + 4.5470025998E-2f;
+    p = p * z + 7.4953002686E-2f;
+    p = p * z + 1.6666752422E-1f;
+    p = p * z;
+    p = p * w;
+    p = p + w;
+    if (flag) { p = p + p; p = 1.5707963267948966192f - p; }
+    return neg ? -p : p;
+}
+RT_FORCEINLINE float rt_acosf(float x)
+{
+    if (x != x) return x;
+    if (x < -1.0f || x > 1.0f) return (x - x) / (x - x);   // NaN: a non-unit sphere normal (w-lane pollution) gets here; f2i_gpu then reads texel row 0
+    if (x < -0.5f) return 3.14159265358979323846f - 2.0f * rt_asinf(sqrtf(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * rt_asinf(sqrtf(0.5f * (1.0f - x)));
+    return 1.5707963267948966192f - rt_asinf(x);
+}
+RT_FORCEINLINE float rt_atanf(float x)
+{
+    const bool neg = x < 0.0f;
+    float a = neg ? -x : x, y;
+    if (a > 2.414213562373095f) { y = 1.5707963267948966192f; a = -(1.0f / a); }
+    else if (a > 0.4142135623730950f) { y = 0.7853981633974483096f; a = (a - 1.0f) / (a + 1.0f); }
+    else y = 0.0f;
+    const float z = a * a;
+    float p = 8.05374449538e-2f * z - 1.38776856032E-1f;
+    p = p * z + 1.99777106478E-1f;
+    p = p * z - 3.33329491539E-1f;
+    p = p * z;
+    p = p * a;
+    p = p + a;
+    y = y + p;
+    return neg ? -y : y;
+}
+RT_FORCEINLINE float rt_atan2f(float y, float x)
+{
+    if (x != x || y != y) return x + y;
+    if (x == 0.0f) {
+        if (y == 0.0f) return signbit(x) ? copysignf(3.14159265358979323846f, y) : y;
+        return y > 0.0f ? 1.5707963267948966192f : -1.5707963267948966192f;
+    }
+    float z = rt_atanf(y / x);
+    if (x < 0.0f) z = signbit(y) ? z - 3.14159265358979323846f : z + 3.14159265358979323846f;
+    return z;
+}
+
 // ------------------------------------------------------------------ RNG (util.cl:50-59)
 RT_FORCEINLINE uint32_t rng_next(uint32_t& s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
 RT_FORCEINLINE float rnd_float(uint32_t& s) { return (float)rng_next(s) * 2.3283064365387e-10f; }
@@ -540,7 +664,7 @@ RT_FORCEINLINE void primary_ray(const RtCamera& cam, int x, int y, int W, int H,
         if (r2 > 1.0f) { O = splat(0.0f); D = splat(0.0f); return; }
         float rr = sqrtf(r2);
         float psi = rr * cam.fov * kPi / 180.0f;
-        float sinPsi = sinf(psi), cosPsi = cosf(psi);
+        float sinPsi = rt_sinf(psi), cosPsi = rt_cosf(psi);
         float sinAlpha = u / rr, cosAlpha = v / rr;
         D = sub4(add4(muls(ld4(cam.up), sinPsi * cosAlpha), muls(ld4(cam.right), sinPsi * sinAlpha)), muls(ld4(cam.forward), cosPsi));
         O = ld4(cam.origin);
@@ -925,8 +1049,8 @@ RT_FORCEINLINE float4 albedo_of(const DevScene& sc, const RtPrimitive* prim, con
             int x = f2i_gpu(ux * (float)texW), y = f2i_gpu(uy * (float)texH);
             albedo = texel(sc, (long long)texIdx + x + (long long)y * texW);
         } else if (type == RT_PRIM_SPHERE) {
-            float ux = (float)((1 + atan2f(ray.N.z, ray.N.x) / 3.14159265358979323846) * 0.5);
-            float uy = acosf(ray.N.y) / 3.14159265358979323846f;
+            float ux = (float)((1 + rt_atan2f(ray.N.z, ray.N.x) / 3.14159265358979323846) * 0.5);
+            float uy = rt_acosf(ray.N.y) / 3.14159265358979323846f;
             int x = f2i_gpu(ux * (float)texW), y = f2i_gpu(uy * (float)texH);
             albedo = texel(sc, (long long)texIdx + x + (long long)y * texW);
         } else {
@@ -946,7 +1070,7 @@ RT_FORCEINLINE float4 random_point_on(const RtPrimitive* p, uint32_t& seed) // p
         float theta = rnd_abs(seed) * 2.0f * kPi;
         float u = rnd_abs(seed) * 2.0f - 1.0f;
         float pre = sqrtf(1 - u * u);
-        float x = cosf(theta) * pre, y = sinf(theta) * pre;
+        float x = rt_cosf(theta) * pre, y = rt_sinf(theta) * pre;
         return add4(muls(mk4(x, y, u, 0.0f), p->obj.sphere.r), ld4(p->obj.sphere.pos));
     }
     const float4 v0 = ld4(p->obj.triangle.v0), v1 = ld4(p->obj.triangle.v1), v2 = ld4(p->obj.triangle.v2);
@@ -989,9 +1113,9 @@ RT_FORCEINLINE float fresnel(SRay& ray, const RtMaterial* mat, float4& outT) // 
     float n1 = mat->n1, n2 = mat->n2;
     if (ray.inside) {
         n1 = mat->n2; n2 = mat->n1;
-        ray.inten.x *= expf(-mat->absorption.x * ray.t);
-        ray.inten.y *= expf(-mat->absorption.y * ray.t);
-        ray.inten.z *= expf(-mat->absorption.z * ray.t);
+        ray.inten.x *= rt_expf(-mat->absorption.x * ray.t);
+        ray.inten.y *= rt_expf(-mat->absorption.y * ray.t);
+        ray.inten.z *= rt_expf(-mat->absorption.z * ray.t);
     }
     float frac = n1 * (1 / n2);
     float k = 1 - frac * frac * (1 - costhetai * costhetai);

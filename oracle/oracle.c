@@ -70,6 +70,130 @@ static inline f4 normalize4(f4 v)
     return muls(v, r);
 }
 
+/* ---------------------------------------------------------------- transcendentals
+ * exp (Beer's law), sin / cos (fisheye camera, sphere lights), acos / atan2 (sphere texture lookup) come from different math
+ * libraries on a CPU and on the GPU (ROCm's device library leans on hardware v_exp / v_sin approximations), so calling libm here
+ * and the device library there can never agree bit for bit - and a last-bit difference in a Fresnel draw or a texel index flips a
+ * whole path.  Oracle and HIP path therefore both evaluate the SAME sequence of IEEE + - * / sqrt operations: the single-precision
+ * Cephes algorithms (S. Moshier, cephes/single: expf.c, sinf.c, asinf.c, atanf.c - published coefficients and reduction constants),
+ * each written out independently here and in rt355_kernels.h.  Against the reference's own kernels they differ by a few ulp, like
+ * normalize() does; tests/test_gpu_reference.py bounds that. */
+static inline float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static float orc_expf(float x)
+{
+    if (x != x) return x;
+    if (x > 88.7228394f) return INFINITY;
+    if (x < -103.972076f) return 0.0f;
+    float n = floorf(x * 1.44269504088896341f + 0.5f);          /* round(x / ln 2) */
+    float r = x - n * 0.693359375f;                              /* Cody-Waite: ln 2 = C1 + C2 */
+    r = r - n * -2.12194440e-4f;
+    float z = r * r;
+    float p = 1.9875691500E-4f;
+    p = p * r + 1.3981999507E-3f;
+    p = p * r + 8.3334519073E-3f;
+    p = p * r + 4.1665795894E-2f;
+    p = p * r + 1.6666665459E-1f;
+    p = p * r + 5.0000001201E-1f;
+    float e = p * z;
+    e = e + r;
+    e = e + 1.0f;
+    int k = (int)n;                                              /* e * 2^k in steps that stay representable */
+    if (k > 127) { e = e * 0x1p127f; k -= 127; }
+    else if (k < -126) { e = e * 0x1p-126f; k += 126; }
+    return e * bits_f32((uint32_t)(k + 127) << 23);
+}
+/* argument reduction of sinf / cosf: octant j of |x| (made even-up), remainder in [-pi/4, pi/4] by three-term Cody-Waite */
+static float orc_sincos_reduce(float ax, int* jOut)
+{
+    int j = (int)(1.27323954473516f * ax);                       /* 4 / pi */
+    float y = (float)j;
+    if (j & 1) { j += 1; y = y + 1.0f; }
+    *jOut = j & 7;
+    float r = ax - y * 0.78515625f;
+    r = r - y * 2.4187564849853515625e-4f;
+    r = r - y * 3.77489497744594108e-8f;
+    return r;
+}
+static inline float orc_sin_poly(float x, float z) { float p = -1.9515295891E-4f * z + 8.3321608736E-3f; p = p * z - 1.6666654611E-1f; p = p * z; p = p * x; return p + x; }
+static inline float orc_cos_poly(float z) { float p = 2.443315711809948E-005f * z - 1.388731625493765E-003f; p = p * z + 4.166664568298827E-002f; p = p * z; p = p * z; p = p - 0.5f * z; return p + 1.0f; }
+static float orc_sinf(float x)
+{
+    if (x != x) return x;
+    int neg = x < 0.0f; float ax = neg ? -x : x;
+    if (ax > 8192.0f) return 0.0f;                               /* total loss of precision (cephes) */
+    int j; float r = orc_sincos_reduce(ax, &j);
+    if (j > 3) { neg = !neg; j -= 4; }
+    float z = r * r;
+    float y = (j == 1 || j == 2) ? orc_cos_poly(z) : orc_sin_poly(r, z);
+    return neg ? -y : y;
+}
+static float orc_cosf(float x)
+{
+    if (x != x) return x;
+    float ax = x < 0.0f ? -x : x;
+    if (ax > 8192.0f) return 0.0f;
+    int j; float r = orc_sincos_reduce(ax, &j);
+    int neg = 0;
+    if (j > 3) { neg = !neg; j -= 4; }
+    if (j > 1) neg = !neg;
+    float z = r * r;
+    float y = (j == 1 || j == 2) ? orc_sin_poly(r, z) : orc_cos_poly(z);
+    return neg ? -y : y;
+}
+static float orc_asinf(float x)                                   /* |x| <= 1 */
+{
+    int neg = x < 0.0f; float a = neg ? -x : x;
+    if (a > 1.0f) return (x - x) / (x - x);                      /* NaN */
+    if (a < 1.0e-4f) return x;
+    float z, w; int flag = 0;
+    if (a > 0.5f) { z = 0.5f * (1.0f - a); w = sqrtf(z); flag = 1; }
+    else { w = a; z = w * w; }
+    float p = 4.2163199048E-2f * z + 2.4181311049E-2f;
+    p = p * z + 4.5470025998E-2f;
+    p = p * z + 7.4953002686E-2f;
+    p = p * z + 1.6666752422E-1f;
+    p = p * z;
+    p = p * w;
+    p = p + w;
+    if (flag) { p = p + p; p = 1.5707963267948966192f - p; }
+    return neg ? -p : p;
+}
+static float orc_acosf(float x)
+{
+    if (x != x) return x;
+    if (x < -1.0f || x > 1.0f) return (x - x) / (x - x);         /* NaN: a non-unit sphere normal (w-lane pollution) gets here */
+    if (x < -0.5f) return 3.14159265358979323846f - 2.0f * orc_asinf(sqrtf(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * orc_asinf(sqrtf(0.5f * (1.0f - x)));
+    return 1.5707963267948966192f - orc_asinf(x);
+}
+static float orc_atanf(float x)
+{
+    int neg = x < 0.0f; float a = neg ? -x : x, y;
+    if (a > 2.414213562373095f) { y = 1.5707963267948966192f; a = -(1.0f / a); }
+    else if (a > 0.4142135623730950f) { y = 0.7853981633974483096f; a = (a - 1.0f) / (a + 1.0f); }
+    else y = 0.0f;
+    float z = a * a;
+    float p = 8.05374449538e-2f * z - 1.38776856032E-1f;
+    p = p * z + 1.99777106478E-1f;
+    p = p * z - 3.33329491539E-1f;
+    p = p * z;
+    p = p * a;
+    p = p + a;
+    y = y + p;
+    return neg ? -y : y;
+}
+static float orc_atan2f(float y, float x)
+{
+    if (x != x || y != y) return x + y;
+    if (x == 0.0f) {
+        if (y == 0.0f) return signbit(x) ? copysignf(3.14159265358979323846f, y) : y;
+        return y > 0.0f ? 1.5707963267948966192f : -1.5707963267948966192f;
+    }
+    float z = orc_atanf(y / x);
+    if (x < 0.0f) z = signbit(y) ? z - 3.14159265358979323846f : z + 3.14159265358979323846f;
+    return z;
+}
+
 /* ---------------------------------------------------------------- RNG (util.cl:50-59) */
 uint32_t orc_xorshift32(uint32_t* s)
 {
@@ -155,7 +279,7 @@ static void primary_ray(RtRay* r, int x, int y, const RtCamera* cam, int aa, int
         if (r2 > 1.0f) { init_ray(r, splat(0.0f), splat(0.0f)); return; }
         float rr = sqrtf(r2);
         float psi = rr * cam->fov * 3.14159265358979323846f / 180.0f; /* r*fov*M_PI_F/180 */
-        float sinPsi = sinf(psi), cosPsi = cosf(psi);
+        float sinPsi = orc_sinf(psi), cosPsi = orc_cosf(psi);
         float sinAlpha = u / rr, cosAlpha = v / rr;
         f4 D = sub4(add4(muls(cam->up, sinPsi * cosAlpha), muls(cam->right, sinPsi * sinAlpha)), muls(cam->forward, cosPsi));
         init_ray(r, cam->origin, D);
@@ -265,8 +389,8 @@ static f4 albedo_of(const RtRay* ray, const OrcScene* sc) /* primitives.cl:107-1
             albedo = texel(sc, (long long)mat->texIdx + x + (long long)y * mat->texW);
         } break;
         case RT_PRIM_SPHERE: {
-            float ux = (float)((1 + atan2f(ray->N.z, ray->N.x) / 3.14159265358979323846) * 0.5); /* atan2pi, double 0.5 */
-            float uy = acosf(ray->N.y) / 3.14159265358979323846f;
+            float ux = (float)((1 + orc_atan2f(ray->N.z, ray->N.x) / 3.14159265358979323846) * 0.5); /* atan2pi, double 0.5 */
+            float uy = orc_acosf(ray->N.y) / 3.14159265358979323846f;
             int x = f2i_gpu(ux * (float)mat->texW), y = f2i_gpu(uy * (float)mat->texH);
             albedo = texel(sc, (long long)mat->texIdx + x + (long long)y * mat->texW);
         } break;
@@ -292,7 +416,7 @@ static f4 random_point_on(const RtPrimitive* p, uint32_t* seed) /* primitives.cl
         float theta = rnd_abs(seed) * 2.0f * 3.14159265358979323846f;
         float u = rnd_abs(seed) * 2.0f - 1.0f;
         float pre = sqrtf(1 - u * u);
-        float x = cosf(theta) * pre, y = sinf(theta) * pre;
+        float x = orc_cosf(theta) * pre, y = orc_sinf(theta) * pre;
         return add4(muls(v4(x, y, u, 0.0f), s->r), s->pos);
     }
     const RtTriangle* t = &p->obj.triangle;
@@ -443,9 +567,9 @@ static float fresnel(RtRay* ray, const RtMaterial* mat, f4* outT) /* glass.cl:4-
     float n1 = mat->n1, n2 = mat->n2;
     if (ray->inside) {
         n1 = mat->n2; n2 = mat->n1;
-        ray->intensity.x *= expf(-mat->absorption.x * ray->t); /* beersLaw, glass.cl:4-9 */
-        ray->intensity.y *= expf(-mat->absorption.y * ray->t);
-        ray->intensity.z *= expf(-mat->absorption.z * ray->t);
+        ray->intensity.x *= orc_expf(-mat->absorption.x * ray->t); /* beersLaw, glass.cl:4-9 */
+        ray->intensity.y *= orc_expf(-mat->absorption.y * ray->t);
+        ray->intensity.z *= orc_expf(-mat->absorption.z * ray->t);
     }
     float frac = n1 * (1 / n2);
     float k = 1 - frac * frac * (1 - costhetai * costhetai);
