@@ -638,7 +638,12 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
     else if (ctx->persist && ctx->cfg.extend_variant != 5)
         // bounce 0 through the same kernel with one workgroup per 256 rays: its "queue not longer than the grid" branch is the plain
         // one-ray-per-lane loop without the TLAS code of k_extend (60 instead of 86 VGPRs: 8 instead of 5 waves per SIMD)
-        LAUNCH(ctx, ST_EXTEND, (k_trace_persist<false>), grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+    {
+        // bounce 0: wave-uniform node records come through the scalar cache (traverse_bvh2_packed_coherent; RT355_COHERENT=0 switches it off for A/B runs)
+        static const bool coherent = !(getenv("RT355_COHERENT") && atoi(getenv("RT355_COHERENT")) == 0);
+        if (coherent && bounce == 0) LAUNCH(ctx, ST_EXTEND, (k_trace_persist<false, true>), grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+        else LAUNCH(ctx, ST_EXTEND, (k_trace_persist<false>), grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+    }
     else if (ctx->cfg.accel == RT_ACCEL_BVH4 && ctx->layout == 1)
         LAUNCH(ctx, ST_EXTEND, (k_extend<RT_ACCEL_BVH4, 1>), grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, renderBVH);
     else if (ctx->cfg.accel == RT_ACCEL_BVH4)

@@ -471,6 +471,52 @@ RT_FORCEINLINE int traverse_bvh2_packed(const DevScene& sc, TRay& r, uint32_t ro
     return steps;
 }
 
+// Primary rays (an 8x8 pixel tile per wave): for the first ~10 levels every lane of the wave sits on the SAME node.  While that holds
+// the 64-byte pair record is fetched once through the scalar cache (constant address space + a wave-uniform index = s_load) instead of
+// 64 times through the vector memory pipeline; arithmetic, visit order, `steps` and counters are those of traverse_bvh2_packed.
+typedef float fvec4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) fvec4* ConstF4;
+RT_FORCEINLINE int traverse_bvh2_packed_coherent(const DevScene& sc, TRay& r, uint32_t rootEntry, uint32_t* stk, WorkCtr& wc)
+{
+    uint32_t cur = rootEntry, sp = 0;
+    int steps = 0;
+    const float tLight = r.t;
+    const ConstF4 cpairs = (ConstF4)(uintptr_t)sc.pairs;
+    for (;;) {
+        if (cur & kLeafBit) {
+            const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
+            for (uint32_t i = 0; i < count; i++) { wc.prim++; test_tri_packed(sc, first + i, r); }
+            if (sp == 0) break;
+            cur = STK(--sp);
+            continue;
+        }
+        wc.node++;
+        float4 q0, q1, q2, q3;
+        const uint32_t ucur = __builtin_amdgcn_readfirstlane(cur);
+        if (__ballot(cur != ucur) == 0ull) {   // every lane that is on an interior node right now is on this one
+            const ConstF4 p = cpairs + (size_t)ucur * 4;
+            const fvec4 a = p[0], b = p[1], c = p[2], d = p[3];
+            q0 = mk4(a.x, a.y, a.z, a.w); q1 = mk4(b.x, b.y, b.z, b.w); q2 = mk4(c.x, c.y, c.z, c.w); q3 = mk4(d.x, d.y, d.z, d.w);
+        } else {
+            const float4* p = sc.pairs + (size_t)cur * 4;
+            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+        }
+        float d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
+        float d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
+        uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
+        if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t e = e1; e1 = e2; e2 = e; }
+        if (d1 >= tLight) {
+            if (sp == 0) break;
+            cur = STK(--sp);
+        } else {
+            steps++;
+            cur = e1;
+            if (d2 < tLight) { STK(sp) = e2; sp++; steps++; }
+        }
+    }
+    return steps;
+}
+
 // BVH4 traversal, bvh.cl:55-96 (children visited in slot order, all four distances taken
 // at node entry).
 template <bool OCC>
@@ -723,7 +769,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int
 // launch does not start with thousands of waves hammering one counter); further chunks are dequeued.
 struct PersistTune { int chunk, refill, inner, leafK; };   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path
 
-template <bool OCC>
+template <bool OCC, bool COH = false>
 __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues q, int b0, int b1, int renderBVH, PersistTune tune)
 {
     const int kChunk = tune.chunk, kRefill = tune.refill, kInner = tune.inner, kLeafK = tune.leafK;
@@ -766,7 +812,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
             r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
             r.t = tmax; r.prim = -1; r.u = 0.0f; r.v = 0.0f;
             rays = 1; wc.inst = 1;
-            const int st = traverse_bvh2_packed<OCC>(sc, r, rootEntry, stk, wc);
+            const int st = COH ? traverse_bvh2_packed_coherent(sc, r, rootEntry, stk, wc) : traverse_bvh2_packed<OCC>(sc, r, rootEntry, stk, wc);
             if (OCC) { if (st == -1) q.sC[qFirst + idx] = splat(0.0f); }
             else {
                 q.hit[idx] = mk4(r.t, __int_as_float(r.prim), r.u, r.v);

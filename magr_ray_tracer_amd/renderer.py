@@ -71,7 +71,7 @@ class Device:
         if k["persist4"]:
             return "k_trace_persist4<false>"
         if k["persist"]:
-            return "k_trace_persist<false>"
+            return "k_trace_persist<false> (bounce 0: <false, true>, node records of wave-uniform visits through the scalar cache)"
         return "k_extend<%s, %d>" % ("RT_ACCEL_BVH4" if self.accel == _lib.ACCEL_BVH4 else "RT_ACCEL_BVH2", k["layout"])
 
     def set_seeds(self, seeds):
