@@ -135,7 +135,7 @@ def main():
         out = []
         for p in rdist.plans(args.shard, W, H, rank, world, m, lanes):
             d = Device(W, H, y0=p["y0"], y1=p["y1"], accel=accel, device=local, profile=0 if args.no_profile else 1,
-                       extend_variant=args.extend_variant)
+                       extend_variant=args.extend_variant, shade_blocks_per_cu=1 if lanes > 1 else 0)   # several streams share the GPU: leave room
             d.upload(sa)
             d.bind_accum(accums[m])
             seeds = np.zeros(p["seed_count"], np.uint32)
@@ -223,11 +223,22 @@ def main():
     value_single = None
     if args.shard == "samples":
         barrier()
+        solo = dev
+        if lanes > 1:     # the lanes' contexts are configured for sharing the GPU; the single-Renderer figure gets a context of its own
+            solo = Device(W, H, accel=accel, device=local, profile=0 if args.no_profile else 1, extend_variant=args.extend_variant)
+            solo.upload(sa)
+            solo.bind_accum(torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}"))
+            seeds = np.zeros(W * H, np.uint32)
+            _seed_stream(seeds, rdist.plan("samples", W, H, rank, world)["seed_first"])
+            solo.set_seeds(seeds)
+            solo.render(cam, 2)
+            solo.synchronize()
         n1 = max(16, min(args.steps, 64))
         t0 = time.perf_counter()
-        dev.render(cam, n1)
-        dev.synchronize()
+        solo.render(cam, n1)
+        solo.synchronize()
         value_single = W * H * n1 / max_over_ranks(time.perf_counter() - t0) / 1e6 * world
+        dev = solo
         if not args.no_profile and rank == 0:   # 16 more frames of that context with every stage bracketed (kernels undisturbed)
             dev.set_profile(2)
             dev.reset_stage_times()
@@ -313,6 +324,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sa, cam, W, H, accel)
         print(json.dumps(out), flush=True)
     group.close()
+    if dev not in group.devs:
+        dev.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

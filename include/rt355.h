@@ -53,7 +53,9 @@ typedef struct RtConfig {
                                  * one ray per lane, 2 = derived layout, one ray per lane                            */
     int32_t profile;            /* HIP-event brackets on the context's stream: 0 none, 1 extend launches only
                                  * (what the roofline needs; ~1 % overhead), 2 every stage launch (~3.5 %)        */
-    int32_t reserved[3];
+    int32_t shade_blocks_per_cu;/* k_shade workgroups per CU: 0 = what the CUs hold (2, best for one context with the GPU to itself);
+                                 * 1 leaves room for the kernels of other contexts (best when several sample streams share the GPU) */
+    int32_t reserved[2];
 } RtConfig;
 
 /* Device-side work counters (per-kernel-family totals since the last rt_reset_counters).

@@ -41,8 +41,9 @@ StageTimes = np.dtype([(n, "<f8") for n in ("generate_ms", "extend_ms", "shade_m
                       [(n, "<i8") for n in ("generate_launches", "extend_launches", "shade_launches", "compact_launches",
                                             "connect_launches", "accumulate_launches")])
 Config = np.dtype([(n, "<i4") for n in ("width", "height", "y0", "y1", "max_bounces", "shading", "sampling", "accel",
-                                         "russian_roulette", "filter_fireflies", "device", "extend_variant", "profile")] +
-                  [("reserved", "<i4", 3)])
+                                         "russian_roulette", "filter_fireflies", "device", "extend_variant", "profile",
+                                         "shade_blocks_per_cu")] +
+                  [("reserved", "<i4", 2)])
 
 KernelInfo = np.dtype([(n, "<i4") for n in ("layout", "persist", "persist4", "stack_entries", "persist_grid", "persist_grid_connect",
                                              "shade_grid", "n_blas")])

@@ -187,6 +187,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
         else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<false>, kTile, 0));
         perCU = std::min(perCU, kAdmitAnySgpr);
         ctx->shadeGrid = prop.multiProcessorCount * std::max(1, perCU);
+        if (c.shade_blocks_per_cu > 0 && c.shade_blocks_per_cu <= 16) ctx->shadeGrid = prop.multiProcessorCount * c.shade_blocks_per_cu;
         if (const char* g = getenv("RT355_SHADE_PER_CU")) { int v = atoi(g); if (v > 0 && v <= 16) ctx->shadeGrid = prop.multiProcessorCount * v; }   // tuning / over-subscription tests
     }
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -702,7 +703,7 @@ extern "C" int rt_stage_connect(RtCtx* ctx, int32_t b0, int32_t b1)
         LAUNCH(ctx, ST_CONNECT, (k_connect<RT_ACCEL_BVH2, 0>), grid_for(cap), stack_bytes(ctx), ctx->sc, ctx->q, b0, b1);
     ev_begin(ctx, ST_ACCUM);
     for (int b = b0; b <= b1; b++)
-        hipLaunchKernelGGL(k_accumulate, grid_for(ctx->nPix), dim3(kBlock), 0, ctx->stream, ctx->q, b);
+        hipLaunchKernelGGL(k_accumulate, dim3(std::min(grid_for(ctx->nPix).x, 2048u)), dim3(kBlock), 0, ctx->stream, ctx->q, b);
     ev_end(ctx, ST_ACCUM);
     HIPCHK(hipGetLastError());
     return RT_OK;

@@ -1522,12 +1522,13 @@ __global__ __launch_bounds__(kBlock) void k_connect(DevScene sc, DevQueues q, in
 __global__ __launch_bounds__(kBlock) void k_accumulate(DevQueues q, int bounce)
 {
     const int first = q.nShadow[bounce], n = q.nShadow[bounce + 1] - first;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float4 c = q.sC[first + i];
-    if (c.x == 0.0f && c.y == 0.0f && c.z == 0.0f && c.w == 0.0f) return;
-    const int pix = __float_as_int(q.sB[first + i].w);
-    q.accum[pix] = add4(q.accum[pix], c);
+    // grid-stride: the launch is sized for a typical queue, not for the worst case of one shadow ray per pixel
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float4 c = q.sC[first + i];
+        if (c.x == 0.0f && c.y == 0.0f && c.z == 0.0f && c.w == 0.0f) continue;
+        const int pix = __float_as_int(q.sB[first + i].w);
+        q.accum[pix] = add4(q.accum[pix], c);
+    }
 }
 
 // ------------------------------------------------------------------ k_focus (wavefront.cl:203-224)
