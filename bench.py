@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stage launches with HIP events")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (default); gloo only for rehearsals")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses GPU 0 (requires --backend gloo)")
+    ap.add_argument("--no-single", action="store_true", help="skip the untimed single-context pass (profiler runs: only the timed workload's launches)")
     ap.add_argument("--no-repeat", action="store_true", help="time the K-step region once, however short it is")
     ap.add_argument("--dump-accum", default=None, help="rank 0 writes the reduced accumulator (npy) here after the timed region")
     return ap.parse_args()
@@ -221,7 +222,7 @@ def main():
     # ---- untimed: ONE context with the GPU to itself (the reference's own shape: one Renderer) -----------------------------------
     single, stage_tab, con = {}, {}, {}
     value_single = None
-    if args.shard == "samples":
+    if args.shard == "samples" and not args.no_single:
         barrier()
         solo = dev
         if lanes > 1:     # the lanes' contexts are configured for sharing the GPU; the single-Renderer figure gets a context of its own
