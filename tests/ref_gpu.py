@@ -137,6 +137,71 @@ class RefGPU:
         nOut, nSh = int(st["numOutRays"]), int(st["shadowRays"])
         return self.rd(d_out, W.Ray, n)[:nOut].copy(), self.rd(d_sh, W.ShadowRay, n)[:nSh].copy(), self.rd(d_seeds, np.uint32, len(seeds))
 
+    def shade_s1(self, rays, seeds):
+        """The reference's shade kernel under schedule S1 (queue slot g is shaded with RNG stream seeds[g], survivors keep their
+        order): one launch of ONE work-item per ray, in slot order, with the ray / seed pointers advanced to the slot and the
+        extension-ray pointer to the number appended so far (the kernel resets numOutRays itself, wavefront.cl:90-93; the shadow
+        counter keeps running).  A legal execution of the reference - and the schedule the HIP path implements."""
+        n = len(rays)
+        d_in, d_out, d_sh, d_seeds = self.dbuf(rays), self.dbuf(nbytes=128 * max(n, 1)), self.dbuf(nbytes=96 * max(n, 1)), self.dbuf(seeds)
+        n_out = n_sh = 0
+        for slot in range(n):
+            self.set_counts(0, 1, n_sh)
+            self.launch("shade", 1, 1, [C.c_void_p(d_in.value + 128 * slot), C.c_void_p(d_out.value + 128 * n_out), d_sh, self.prims, self.tex,
+                                        self.mats, self.lights, self.d_set, self.accum, C.c_void_p(d_seeds.value + 4 * slot)])
+            st = self.get_settings()
+            n_out += int(st["numOutRays"])
+            n_sh = int(st["shadowRays"])
+        return (self.rd(d_out, W.Ray, max(n, 1))[:n_out].copy(), self.rd(d_sh, W.ShadowRay, max(n, 1))[:n_sh].copy(),
+                self.rd(d_seeds, np.uint32, len(seeds)))
+
+    def frame_s1(self, cam, y0, y1, shading=1, russian_roulette=True, bounces=7):
+        """One whole Renderer::RayTrace() (renderer.cpp:64-94) over rows [y0, y1) through the reference's own kernels under schedule S1:
+        generate; 7 x { extend (one work-group), shade (one single-work-item launch per queue slot, RNG stream seeds[slot], survivors
+        appended in slot order), [connect if !RR and NEE], swap }; [connect if RR] - connect likewise one launch per shadow ray in
+        queue order, so a pixel's contributions are added in (bounce, slot) order.  This is the schedule the HIP path implements:
+        its accumulator and per-slot RNG states can be compared with this frame directly."""
+        first, n, n_all = y0 * REF_W, (y1 - y0) * REF_W, y1 * REF_W
+        assert n_all % 256 == 0
+        from oracle.oracle_py import seed_stream
+        d_all, d_seeds_all = self.dbuf(nbytes=128 * n_all), self.dbuf(seed_stream(0, n_all))
+        self.set_counts(0, n, 0)
+        self.launch("generate", n_all, 256, [d_all, self.d_set, d_seeds_all, np.ascontiguousarray(cam).reshape(1)])
+        ray1, ray2 = C.c_void_p(d_all.value + 128 * first), self.dbuf(nbytes=128 * n)
+        d_seeds = C.c_void_p(d_seeds_all.value + 4 * first)
+        d_sh = self.dbuf(nbytes=96 * n * bounces)
+        self.clear_accum()
+        nee = shading == 1
+        counts, n_in, n_sh = [], n, 0
+
+        def connect_all(n_shadow):
+            for k in range(n_shadow):
+                self.set_counts(0, 0, 1)
+                self.launch("connect", 1, 1, [C.c_void_p(d_sh.value + 96 * k), self.tlas, self.blas, self.nodes, self.idx, self.prims, self.mats, self.d_set, self.accum])
+
+        for b in range(bounces):
+            self.set_counts(0, n_in, n_sh)
+            self.launch("extend", 256, 256, [ray1, self.prims, self.tlas, self.blas, self.nodes, self.idx, self.accum, self.d_set])
+            if not russian_roulette:
+                n_sh = 0                                               # extend resets the counter (wavefront.cl:54-56)
+            counts.append(n_in)
+            n_out = 0
+            for slot in range(n_in):
+                self.set_counts(0, 1, n_sh)
+                self.launch("shade", 1, 1, [C.c_void_p(ray1.value + 128 * slot), C.c_void_p(ray2.value + 128 * n_out), d_sh, self.prims, self.tex,
+                                            self.mats, self.lights, self.d_set, self.accum, C.c_void_p(d_seeds.value + 4 * slot)])
+                st = self.get_settings()
+                n_out += int(st["numOutRays"])
+                n_sh = int(st["shadowRays"])
+            if not russian_roulette and nee:
+                connect_all(n_sh)
+            ray1, ray2 = ray2, ray1
+            n_in = n_out
+        if russian_roulette and nee:
+            connect_all(n_sh)
+        return dict(n_in=counts, n_left=n_in, n_shadow=n_sh, seeds=self.rd(d_seeds, np.uint32, n),
+                    accum=self.rd(self.accum, np.float32, 4 * REF_W * y1).reshape(y1 * REF_W, 4)[first:].copy())
+
     def connect_s0(self, shadow):
         d_sh = self.dbuf(shadow)
         self.set_counts(0, 0, len(shadow))

@@ -1029,3 +1029,62 @@ def test_scenes_with_transcendentals_are_bit_exact(case):
     assert np.array_equal(d.get_seeds(), seeds)
     _ctr_equal(d.counters(), e, c)
     d.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_random_mixed_scenes(seed, big=False):
+    """Random scenes with everything the path supports at once - triangle soups, diffuse / mirror / glass / textured / emissive spheres,
+    textured triangles with wrapping uv, glass triangles with absorption, triangle and sphere lights, pinhole or fisheye camera, every
+    kernel variant, SBVH - bit-exact against the oracle (accumulator, RNG state, extend counters).  Possible since exp / sin / cos /
+    acos / atan2 are the same IEEE sequences on both sides."""
+    from magr_ray_tracer_amd.scene import Scene, material
+    rng = np.random.default_rng(77000 + seed)
+    s = Scene()
+    s.AddMaterial("a", material(color=rng.random(3)))
+    s.AddMaterial("b", material(color=rng.random(3) * 0.9 + 0.1))
+    s.AddMaterial("m", material(color=rng.random(3), specular=float(rng.choice([0.3, 0.9, 1.0]))))
+    s.AddMaterial("g", material(color=(1, 1, 1), dielectric=True, n1=1.0, n2=float(rng.choice([1.1, 1.33, 1.5, 2.4])), specular=float(rng.choice([0.0, 0.04])),
+                                absorption=tuple(rng.random(3) * float(rng.choice([0.0, 0.2, 2.0])))))
+    s.AddMaterial("l1", material(color=(1, 1, 1), light=True, emittance=tuple(rng.random(3) * 40 + 5)))
+    s.AddMaterial("l2", material(color=(1, 1, 1), light=True, emittance=tuple(rng.random(3) * 10 + 1)))
+    tw, th = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+    tex = np.zeros((th, tw, 4), np.float32)
+    tex[..., :3] = rng.random((th, tw, 3))
+    s.AddTexture("t", tex)
+    n = int(rng.integers(20, 200))
+    c = rng.random((n, 1, 3)) * 8 - 4
+    size = np.where(rng.random((n, 1, 1)) < 0.2, 3.0, 0.8)
+    tris = (c + (rng.random((n, 3, 3)) - 0.5) * size).astype(np.float32)
+    names = rng.choice(["a", "b", "m", "g", "t"], size=n, p=[0.3, 0.25, 0.15, 0.15, 0.15])
+    for k in ("a", "b", "m", "g"):
+        sel = tris[names == k]
+        if len(sel):
+            s.AddTriangles(sel, k)
+    sel = tris[names == "t"]
+    if len(sel):
+        s.AddTriangles(sel, "t", uvs=(rng.random((len(sel), 3, 2)) * 5 - 2).astype(np.float32))
+    for _ in range(int(rng.integers(2, 9))):
+        s.AddSphere(tuple(rng.random(3) * 7 - 3.5), float(rng.random() * 1.2 + 0.15), str(rng.choice(["a", "m", "g", "t", "l2"])))
+    s.AddTriangles(np.array([[[-6, 7, -6], [6, 7, -6], [6, 7, 6]], [[6, 7, 6], [-6, 7, 6], [-6, 7, -6]]], np.float32), "l1", flipNormal=True)
+    s.AddTriangles(np.array([[[-9, -4.5, -9], [9, -4.5, 9], [9, -4.5, -9]], [[-9, -4.5, -9], [-9, -4.5, 9], [9, -4.5, 9]]], np.float32), "b")
+    s.BuildBLAS(0, alpha=float(rng.choice([1.0, 1.0, 0.0])))
+    sa = s.arrays()
+    Wd, Hd = int(rng.integers(17, 200)), int(rng.integers(9, 120))
+    if big:
+        Wd, Hd = int(rng.integers(300, 520)), int(rng.integers(200, 300))
+    v = dict(DEFAULT, accel=int(rng.integers(0, 2)), shading=int(rng.integers(0, 2)), sampling=int(rng.integers(0, 2)),
+             russian_roulette=bool(rng.integers(0, 2)), filter_fireflies=bool(rng.integers(0, 2)))
+    org = rng.random(3) * 6 - 3 + np.array([0, 0, 9.0])
+    cam = scenes.make_camera(Wd, Hd, tuple(org), tuple(np.array([0.0, 0.1, 1.0]) + (rng.random(3) - 0.5) * 0.4), fov=float(rng.integers(40, 120)),
+                             aperture=float(rng.choice([0.0, 0.1])), type=int(rng.random() < 0.25))
+    o = Oracle(sa, Wd, Hd, **v)
+    d = Device(Wd, Hd, **v)
+    d.upload(sa)
+    frames = 3
+    acc, seeds, e, c = o.render(cam, frames)
+    d.seed_default()
+    d.render(cam, frames)
+    assert_bits(d.read_accum(), acc, f"seed {seed}: {n} tris {Wd}x{Hd} {v}")
+    assert np.array_equal(d.get_seeds(), seeds)
+    _ctr_equal(d.counters(), e, c)
+    d.close()

@@ -9,14 +9,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_parity as T  # noqa: E402
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
-big = len(sys.argv) > 3 and sys.argv[3] == "big"
+big = "big" in sys.argv[3:]
+mixed = "mixed" in sys.argv[3:]        # spheres, glass, textures, sphere lights, fisheye (tests/test_gpu_parity.py test_fuzz_random_mixed_scenes)
 if big:
     os.environ["RT355_TUNE"] = "64,20,6,8,1"   # one workgroup per CU: queues above 65,536 rays take the persistent branch
 bad = []
 t = time.time()
 for seed in range(first, first + count):
     try:
-        T.test_fuzz_random_triangle_soups(seed, big)
+        (T.test_fuzz_random_mixed_scenes if mixed else T.test_fuzz_random_triangle_soups)(seed, big)
     except AssertionError as e:
         bad.append((seed, str(e)[:200]))
         print("MISMATCH seed", seed, str(e)[:300], flush=True)
