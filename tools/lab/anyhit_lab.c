@@ -9,7 +9,8 @@ typedef struct { float mn[4], mx[4]; uint32_t first, count; uint32_t pad[2]; } N
 typedef struct { float v0[4], v1[4], v2[4]; float rest[16]; int32_t type, mat; float area; int32_t pad; } Prim; /* 128 B */
 typedef struct { float o[3], tmax, d[3]; int32_t pix; } SRay;
 
-static const Node* N; static const Prim* P; static const uint32_t* IDX;
+static const Node* N; static const Prim* P; static const uint32_t* IDX; static uint32_t* CNT; static float* OCCP;
+static uint32_t count_prims(uint32_t i) { const Node* n = &N[i]; uint32_t c = n->count > 0 ? n->count : count_prims(n->first) + count_prims(n->first + 1); CNT[i] = c; return c; }
 static float area_of(const Node* n) { float x = n->mx[0] - n->mn[0], y = n->mx[1] - n->mn[1], z = n->mx[2] - n->mn[2]; return x * y + y * z + z * x; }
 static float g_exit;
 static float slab(const float* o, const float* r, float t, const Node* n)
@@ -58,6 +59,11 @@ static int trace(const SRay* s, int order, long* nodes, long* tris)
         int swap = 0;
         if (order == 6) swap = x1 < x2;            /* later exit first */
         if (order == 7) swap = fminf(x1, s->tmax) - d1 < fminf(x2, s->tmax) - d2;   /* longer chord first */
+        if (order == 8) swap = CNT[c1] < CNT[c2];                                   /* more primitives first */
+        if (order == 9) swap = CNT[c1] / (area_of(&N[c1]) + 1e-9f) < CNT[c2] / (area_of(&N[c2]) + 1e-9f);   /* denser first */
+        if (order == 10) swap = (fminf(x1, s->tmax) - fmaxf(d1, 0)) * CNT[c1] / (area_of(&N[c1]) + 1e-9f) < (fminf(x2, s->tmax) - fmaxf(d2, 0)) * CNT[c2] / (area_of(&N[c2]) + 1e-9f);
+        if (order == 11) swap = OCCP[c1] < OCCP[c2];                                /* learned: fraction of visiting rays that found their occluder below this node */
+        if (order == 12) swap = (x1 < x2) ? (OCCP[c2] > 0.5f * OCCP[c1]) : !(OCCP[c1] > 0.5f * OCCP[c2]);
         if (order == 0) swap = d1 > d2;
         else if (order == 1) swap = d1 < d2;
         else if (order == 2) swap = area_of(&N[c1]) < area_of(&N[c2]);
@@ -82,8 +88,25 @@ int main(int argc, char** argv)
     if (fread(n, sizeof(Node), hdr[0], f) != (size_t)hdr[0] || fread(p, sizeof(Prim), hdr[1], f) != (size_t)hdr[1] || fread(ix, 4, hdr[2], f) != (size_t)hdr[2] ||
         fread(s, sizeof(SRay), hdr[3], f) != (size_t)hdr[3]) return 2;
     N = n; P = p; IDX = ix;
-    const char* names[] = { "near-first (reference)", "far-first", "larger-area first", "-", "nearer-the-light first", "leaf child first", "later exit first", "longer chord first" };
-    for (int order = 0; order < 8; order++) {
+    const char* names[] = { "near-first (reference)", "far-first", "larger-area first", "-", "nearer-the-light first", "leaf child first", "later exit first", "longer chord first", "more primitives first", "denser first", "chord x density first", "learned hit rate first", "later exit unless much lower hit rate" };
+    CNT = calloc(hdr[0], 4); OCCP = calloc(hdr[0], 4); count_prims(0);
+    {   /* "learned" order: per node, the fraction of the rays that visit it (exhaustive traversal, no early exit) for which some primitive below it occludes - from the first half of the rays */
+        uint32_t* vis = calloc(hdr[0], 4); uint32_t* occ = calloc(hdr[0], 4);
+        for (int i = 0; i < hdr[3] / 2; i++) {
+            const SRay* sr = &s[i]; float r[3] = { 1 / sr->d[0], 1 / sr->d[1], 1 / sr->d[2] };
+            /* recursive exhaustive traversal with explicit stack of (node, state) is overkill: do a post-order via recursion */
+            struct F { uint32_t node; int state; int hit; } st[128]; int sp = 0; st[sp++] = (struct F){ 0, 0, 0 };
+            while (sp) {
+                struct F* f = &st[sp - 1]; const Node* nd = &N[f->node];
+                if (nd->count > 0) { int h = 0; for (uint32_t j = 0; j < nd->count; j++) h |= tri_hit(sr->o, sr->d, sr->tmax, &P[IDX[nd->first + j]]); vis[f->node]++; occ[f->node] += h; int hh = h; sp--; if (sp) st[sp - 1].hit |= hh; continue; }
+                if (f->state == 0) { f->state = 1; if (slab(sr->o, r, sr->tmax, &N[nd->first]) < 1e29f) { st[sp++] = (struct F){ nd->first, 0, 0 }; } continue; }
+                if (f->state == 1) { f->state = 2; if (slab(sr->o, r, sr->tmax, &N[nd->first + 1]) < 1e29f) { st[sp++] = (struct F){ nd->first + 1, 0, 0 }; } continue; }
+                vis[f->node]++; occ[f->node] += f->hit; int hh = f->hit; sp--; if (sp) st[sp - 1].hit |= hh;
+            }
+        }
+        for (int i = 0; i < hdr[0]; i++) OCCP[i] = vis[i] ? (float)occ[i] / vis[i] : 0.0f;
+    }
+    for (int order = 0; order < 13; order++) {
         if (order == 3) continue;
         long nodes[2] = { 0, 0 }, tris[2] = { 0, 0 }, cnt[2] = { 0, 0 };
         for (int i = 0; i < hdr[3]; i++) { long a = 0, b = 0; int h = trace(&s[i], order, &a, &b); nodes[h] += a; tris[h] += b; cnt[h]++; }

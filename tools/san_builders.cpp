@@ -40,12 +40,19 @@ int main()
             s.bvh2->BuildBLAS(true, first);
         }
         s.BuildBVH4();
+        if (it % 3 == 0 && s.blasNodes.size() > 1) {             // a moved instance: TLAS leaf bounds through inverse(invT)
+            float* T = s.blasNodes[1].invT;
+            const float a = uni(0, 6.28f), c = cosf(a), sn = sinf(a), sc = uni(0.5f, 2.f);
+            const float m[16] = { c * sc, 0, sn * sc, uni(-3, 3), 0, sc, 0, uni(-3, 3), -sn * sc, 0, c * sc, uni(-3, 3), 0, 0, 0, 1 };
+            for (int k = 0; k < 16; k++) T[k] = m[k];
+        }
         TLAS t(*s.bvh2);
         t.Build();
         built++;
     }
-    // OBJ reader on mutated text
-    const std::string obj = "mtllib none.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\nf -1/-1 -2/-2 -3/-3 -4\nf 1//1 2//2 4//4\n";
+    // OBJ reader on mutated text (the MTL names a texture that does not exist: LoadModel must report it, not crash)
+    { std::ofstream m("/tmp/san_case.mtl"); m << "newmtl a\nmap_Kd missing_texture.png\nnewmtl b\nKd 1 0 0\n"; }
+    const std::string obj = "mtllib san_case.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\nf -1/-1 -2/-2 -3/-3 -4\nf 1//1 2//2 4//4\n";
     int parsed = 0, rejected = 0;
     for (int it = 0; it < 3000; it++) {
         std::string b = obj;
