@@ -54,7 +54,7 @@ struct RtCtx {
     bool shadeRun[RT_MAX_BOUNCES + 1] = {};           // shade(b) launched since the last k_begin_frame
     bool generated = false;                           // generate launched since the last k_begin_frame
     int stackEntries = RT_BVH2_STACK, persistGrid = 0, persistGridConnect = 0;
-    PersistTune tune{ 112, 24, 6, 8, 0 }, tuneConnect{ 128, 32, 6, 8, 0 }, tune4{ 64, 20, 6, 8, 0 };   // extend (BVH2), connect, extend (BVH4): measured optima (tools/tune_extend.sh, tune_connect.sh, tune_persist.sh)
+    PersistTune tune{ 112, 24, 6, 8 }, tuneConnect{ 128, 32, 6, 8 }, tune4{ 64, 20, 6, 8 };   // extend (BVH2), connect, extend (BVH4): measured optima (tools/tune_extend.sh, tune_connect.sh, tune_persist.sh)
     float4* dPostF = nullptr; uchar4* dPostB = nullptr;   // post-processing outputs (lazy)
     int32_t* dSteps = nullptr;   // per-ray `steps` buffer, only bound while rt_debug_enable_steps is on
     int shadeGrid = 1024;   // workgroups of k_shade (what the CUs hold at once; the kernel does not depend on it); set in rt_create
@@ -201,7 +201,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     for (int k = 0; k < 2; k++) { QA(O[k], n); QA(D[k], n); QA(inten[k], n); QA(meta[k], n); QA(tile[k], nTiles + 2); QA(super[k], nTiles / 64 + 2); QA(supAcc[k], nTiles / 64 + 2); }
     QA(hit, n);
     QA(sA, nS); QA(sB, nS); QA(sC, nS);
-    QA(nRays, RT_MAX_BOUNCES + 2); QA(nShadow, RT_MAX_BOUNCES + 2); QA(cursor, kCursorWords); QA(cursorX, (size_t)kCursorWords * 128); QA(shadeTicket, (size_t)(RT_MAX_BOUNCES + 1) * kTicketClasses * kTicketStride); QA(fault, 1);
+    QA(nRays, RT_MAX_BOUNCES + 2); QA(nShadow, RT_MAX_BOUNCES + 2); QA(cursor, kCursorWords); QA(shadeTicket, (size_t)(RT_MAX_BOUNCES + 1) * kTicketClasses * kTicketStride); QA(fault, 1);
     QA(seeds, n); QA(accum, (size_t)c.width * c.height);
     if (rc == RT_OK) rc = dalloc(bag, &ctx->dSteps, n);
     q.steps = nullptr;
@@ -214,7 +214,6 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     (void)hipMemsetAsync(q.nRays, 0, sizeof(int32_t) * (RT_MAX_BOUNCES + 2), ctx->stream);
     (void)hipMemsetAsync(q.nShadow, 0, sizeof(int32_t) * (RT_MAX_BOUNCES + 2), ctx->stream);
     (void)hipMemsetAsync(q.cursor, 0, sizeof(int32_t) * kCursorWords, ctx->stream);
-    (void)hipMemsetAsync(q.cursorX, 0, sizeof(int32_t) * kCursorWords * 128, ctx->stream);
     (void)hipMemsetAsync(q.shadeTicket, 0, sizeof(int32_t) * (size_t)(RT_MAX_BOUNCES + 1) * kTicketClasses * kTicketStride, ctx->stream);
     (void)hipMemsetAsync(q.fault, 0, sizeof(int32_t), ctx->stream);
     (void)hipMemsetAsync(q.ctrExtend, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
@@ -519,13 +518,12 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner,leafK[,blocksPerCU]" (tuning aid)
             int a = 0, b = 0, c = 0, l = 0, d = 0;
             int k = sscanf(t, "%d,%d,%d,%d,%d", &a, &b, &c, &l, &d);
-            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = ctx->tuneConnect = ctx->tune4 = PersistTune{ a, b, c, l, 0 };
+            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = ctx->tuneConnect = ctx->tune4 = PersistTune{ a, b, c, l };
             if (k == 5 && d > 0) ctx->persistGrid = ctx->persistGridConnect = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount);
         }
-        if (const char* x = getenv("RT355_XCD")) { const int v = atoi(x); ctx->tune.xcd = v & 1; ctx->tuneConnect.xcd = (v >> 1) & 1; }   // experiment: bit 0 extend, bit 1 connect
         if (const char* t = getenv("RT355_TUNE_CONNECT")) { // same fields, connect launches only
             int a = 0, b = 0, c = 0, l = 0;
-            if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l, 0 };
+            if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l };
         }
     }
     ctx->sc = sc;
@@ -630,7 +628,7 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
     int rc = need_scene(ctx, "rt_stage_extend"); if (rc) return rc;
     if (bounce < 0 || bounce > ctx->cfg.max_bounces) return fail(RT_E_INVALID, "rt_stage_extend: bounce %d outside [0, %d]", bounce, ctx->cfg.max_bounces);
     if (ctx->persist || ctx->persist4) { // a queue head is good for one launch per frame; re-arm it if this stage is run again
-        if (ctx->cursorUsed[bounce]) { HIPCHK(hipMemsetAsync(ctx->q.cursor + bounce, 0, sizeof(int32_t), ctx->stream)); HIPCHK(hipMemsetAsync(ctx->q.cursorX + (size_t)bounce * 128, 0, sizeof(int32_t) * 128, ctx->stream)); }
+        if (ctx->cursorUsed[bounce]) HIPCHK(hipMemsetAsync(ctx->q.cursor + bounce, 0, sizeof(int32_t), ctx->stream));
         ctx->cursorUsed[bounce] = true;
     }
     // bounce 0: primary rays are coherent and finish together, refilling buys nothing -> one ray per lane
@@ -688,7 +686,7 @@ extern "C" int rt_stage_connect(RtCtx* ctx, int32_t b0, int32_t b1)
     const int cap = ctx->nPix * (b1 - b0 + 1);
     if (ctx->persist || ctx->persist4) {
         const int ci = (RT_MAX_BOUNCES + 2) + b0;
-        if (ctx->cursorUsed[ci]) { HIPCHK(hipMemsetAsync(ctx->q.cursor + ci, 0, sizeof(int32_t), ctx->stream)); HIPCHK(hipMemsetAsync(ctx->q.cursorX + (size_t)ci * 128, 0, sizeof(int32_t) * 128, ctx->stream)); }
+        if (ctx->cursorUsed[ci]) HIPCHK(hipMemsetAsync(ctx->q.cursor + ci, 0, sizeof(int32_t), ctx->stream));
         ctx->cursorUsed[ci] = true;
     }
     if (ctx->persist4)

@@ -69,7 +69,6 @@ struct DevQueues {
     int32_t* nShadow;  // [RT_MAX_BOUNCES+2]  shadow rays of bounce b occupy [nShadow[b], nShadow[b+1])
     int32_t* fault;    // [1] set to 1 by a kernel whose bounded wait expired (host turns it into RT_E_DEVICE)
     int32_t* cursor;   // [2*(RT_MAX_BOUNCES+2)] work-queue heads of the persistent kernels (extend: [b], connect: [9+b])
-    int32_t* cursorX;  // [2*(RT_MAX_BOUNCES+2)][8][16] the same heads sharded per XCD group (PersistTune.xcd), one cache line each
     int32_t* shadeTicket; // [(RT_MAX_BOUNCES+1) * kTicketClasses * kTicketStride] k_shade's tile tickets, one counter per bounce and class
     uint32_t* seeds;   // one RNG stream per band slot
     float4* accum;     // full frame, indexed by global pixel index
@@ -687,7 +686,6 @@ RT_FORCEINLINE void begin_frame(const DevQueues& q) // renderer.cpp:66-69 (one w
 {
     if (threadIdx.x == 0) { q.nRays[0] = q.nPix; q.nShadow[0] = 0; }
     if (threadIdx.x < kCursorWords) q.cursor[threadIdx.x] = 0;
-    if (threadIdx.x < kCursorWords * 8) q.cursorX[threadIdx.x * 16] = 0;
     for (int k = threadIdx.x; k < (RT_MAX_BOUNCES + 1) * kTicketClasses; k += blockDim.x) q.shadeTicket[(size_t)k * kTicketStride] = 0;
 }
 __global__ void k_begin_frame(DevQueues q) { begin_frame(q); }   // stage-level API; rt_render folds it into k_generate
@@ -769,7 +767,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int
 // all its lanes idle), so the grid always drains.
 // Work distribution: the first chunk of every wave is static (chunk id = global wave id, no atomic, so the
 // launch does not start with thousands of waves hammering one counter); further chunks are dequeued.
-struct PersistTune { int chunk, refill, inner, leafK; int xcd; };   // xcd: shard the queue into 8 contiguous parts, one per group of workgroups that share an XCD   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path
+struct PersistTune { int chunk, refill, inner, leafK; };   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path
 
 template <bool OCC, bool COH = false>
 __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues q, int b0, int b1, int renderBVH, PersistTune tune)
@@ -827,36 +825,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
     }
     int chunkNext = min(waveId * kChunk, n), chunkEnd = min(waveId * kChunk + kChunk, n);   // wave-uniform
     bool exhausted = false;                                                                  // wave-uniform
-    // XCD-sharded queue (experiment, PersistTune.xcd): workgroups b and b + 8 share an XCD under the dispatcher's round-robin placement
-    // (MI355X_MICROARCH.md, workgroup dispatch: a speed heuristic, never relied on for correctness), and the queue is in pixel order, so
-    // giving each group of workgroups one contiguous eighth of the queue keeps an image region's rays - and the deep nodes around their
-    // origins - in one XCD's L2.  A group that runs dry steals from the next group's head.
-    const bool xcdMode = tune.xcd != 0 && (gridDim.x & 7) == 0;
-    const int totalChunks = (n + kChunk - 1) / kChunk, wavesPerGroup = (int)(gridDim.x >> 3) * (kBlock / 64);
-    int victim = (int)(blockIdx.x & 7), tried = 0;                                          // wave-uniform
-    int32_t* cursorX = q.cursorX + (size_t)(OCC ? (RT_MAX_BOUNCES + 2) + b0 : b0) * 128;
-    if (xcdMode) {
-        const int s0 = (int)((long long)totalChunks * victim / 8), e0 = (int)((long long)totalChunks * (victim + 1) / 8);
-        const int c = s0 + (int)(blockIdx.x >> 3) * (kBlock / 64) + (int)(threadIdx.x >> 6);
-        if (c < e0) { chunkNext = c * kChunk; chunkEnd = min(chunkNext + kChunk, n); } else chunkNext = chunkEnd = 0;
-    }
 
     for (;;) {
         const unsigned long long idleMask = __ballot(slot < 0);
         const int nIdle = __popcll(idleMask);
         if (nIdle == 64 && exhausted && chunkNext >= chunkEnd) break;
         if (nIdle >= kRefill && !(exhausted && chunkNext >= chunkEnd)) {
-            if (chunkNext >= chunkEnd && xcdMode) {   // dequeue from the own group's head, then from the other groups'
-                while (tried < 8) {
-                    const int s0 = (int)((long long)totalChunks * victim / 8), e0 = (int)((long long)totalChunks * (victim + 1) / 8);
-                    int c = 0;
-                    if (lane == 0) c = atomicAdd(cursorX + victim * 16, 1);
-                    c = __shfl(c, 0, 64) + s0 + wavesPerGroup;
-                    if (c < e0) { chunkNext = c * kChunk; chunkEnd = min(chunkNext + kChunk, n); break; }
-                    victim = (victim + 1) & 7; tried++;
-                }
-                if (tried >= 8) { exhausted = true; chunkNext = chunkEnd = 0; }
-            } else
             if (chunkNext >= chunkEnd) {           // dequeue a chunk for this wave
                 int c = 0;
                 if (lane == 0) c = atomicAdd(cursor, kChunk);
