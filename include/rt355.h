@@ -55,7 +55,9 @@ typedef struct RtConfig {
                                  * (what the roofline needs; ~1 % overhead), 2 every stage launch (~3.5 %)        */
     int32_t shade_blocks_per_cu;/* k_shade workgroups per CU: 0 = what the CUs hold (2, best for one context with the GPU to itself);
                                  * 1 leaves room for the kernels of other contexts (best when several sample streams share the GPU) */
-    int32_t reserved[2];
+    int32_t persist_blocks_per_cu; /* workgroups per CU of the persistent traversal grids: 0 = what the hardware admits (7 extend / 6 connect);
+                                 * 6 is ~1 % faster when three contexts share the GPU */
+    int32_t reserved[1];
 } RtConfig;
 
 /* Device-side work counters (per-kernel-family totals since the last rt_reset_counters).

@@ -42,8 +42,8 @@ StageTimes = np.dtype([(n, "<f8") for n in ("generate_ms", "extend_ms", "shade_m
                                             "connect_launches", "accumulate_launches")])
 Config = np.dtype([(n, "<i4") for n in ("width", "height", "y0", "y1", "max_bounces", "shading", "sampling", "accel",
                                          "russian_roulette", "filter_fireflies", "device", "extend_variant", "profile",
-                                         "shade_blocks_per_cu")] +
-                  [("reserved", "<i4", 2)])
+                                         "shade_blocks_per_cu", "persist_blocks_per_cu")] +
+                  [("reserved", "<i4", 1)])
 
 KernelInfo = np.dtype([(n, "<i4") for n in ("layout", "persist", "persist4", "stack_entries", "persist_grid", "persist_grid_connect",
                                              "shade_grid", "n_blas")])

@@ -515,6 +515,11 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         // the occupancy query may say more (see rt_create); a surplus workgroup would strand its static first chunk until another exits
         ctx->persistGrid = std::min(ctx->gridMax, std::max(1, std::min(perCU, kAdmit96Sgpr)) * prop.multiProcessorCount);
         ctx->persistGridConnect = std::min(ctx->gridMax, std::max(1, std::min(perCU, kAdmitAnySgpr)) * prop.multiProcessorCount);
+        if (ctx->cfg.persist_blocks_per_cu > 0) {
+            const int d = std::min(ctx->cfg.persist_blocks_per_cu, std::max(1, perCU));
+            ctx->persistGrid = std::min(ctx->persistGrid, std::min(ctx->gridMax, d * prop.multiProcessorCount));
+            ctx->persistGridConnect = std::min(ctx->persistGridConnect, std::min(ctx->gridMax, d * prop.multiProcessorCount));
+        }
         if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner,leafK[,blocksPerCU]" (tuning aid)
             int a = 0, b = 0, c = 0, l = 0, d = 0;
             int k = sscanf(t, "%d,%d,%d,%d,%d", &a, &b, &c, &l, &d);

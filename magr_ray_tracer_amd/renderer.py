@@ -17,14 +17,14 @@ class RtError(RuntimeError):
 class Device:
     def __init__(self, width, height, y0=0, y1=None, shading=_lib.SHADING_NEE, sampling=_lib.SAMPLING_COSINE,
                  accel=_lib.ACCEL_BVH2, russian_roulette=True, filter_fireflies=True, max_bounces=_lib.MAX_BOUNCES,
-                 device=0, profile=False, extend_variant=0, shade_blocks_per_cu=0):
+                 device=0, profile=False, extend_variant=0, shade_blocks_per_cu=0, persist_blocks_per_cu=0):
         self._lib = _lib.device_lib()
         cfg = np.zeros((), dtype=_lib.Config)
         cfg["width"], cfg["height"], cfg["y0"], cfg["y1"] = width, height, y0, height if y1 is None else y1
         cfg["max_bounces"], cfg["shading"], cfg["sampling"], cfg["accel"] = max_bounces, shading, sampling, accel
         cfg["russian_roulette"], cfg["filter_fireflies"] = int(russian_roulette), int(filter_fireflies)
         cfg["device"], cfg["profile"], cfg["extend_variant"] = device, (2 if profile is True else int(profile)), extend_variant
-        cfg["shade_blocks_per_cu"] = shade_blocks_per_cu
+        cfg["shade_blocks_per_cu"], cfg["persist_blocks_per_cu"] = shade_blocks_per_cu, persist_blocks_per_cu
         self.cfg = cfg
         self.width, self.height = width, height
         self.y0, self.y1 = int(cfg["y0"]), int(cfg["y1"])
