@@ -54,7 +54,7 @@ struct RtCtx {
     bool shadeRun[RT_MAX_BOUNCES + 1] = {};           // shade(b) launched since the last k_begin_frame
     bool generated = false;                           // generate launched since the last k_begin_frame
     int stackEntries = RT_BVH2_STACK, persistGrid = 0, persistGridConnect = 0;
-    PersistTune tune{ 112, 24, 6, 8 }, tuneConnect{ 128, 32, 6, 8 }, tune4{ 64, 20, 6, 8 };   // extend (BVH2), connect, extend (BVH4): measured optima (tools/tune_extend.sh, tune_connect.sh, tune_persist.sh)
+    PersistTune tune{ 112, 24, 6, 8 }, tuneConnect{ 128, 32, 6, 16 }, tune4{ 64, 20, 6, 8 };   // extend (BVH2), connect, extend (BVH4): measured optima (tools/tune_extend.sh, tune_connect.sh, tune_persist.sh)
     float4* dPostF = nullptr; uchar4* dPostB = nullptr;   // post-processing outputs (lazy)
     int32_t* dSteps = nullptr;   // per-ray `steps` buffer, only bound while rt_debug_enable_steps is on
     int shadeGrid = 1024;   // workgroups of k_shade (what the CUs hold at once; the kernel does not depend on it); set in rt_create
@@ -519,6 +519,7 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
             const int d = std::min(ctx->cfg.persist_blocks_per_cu, std::max(1, perCU));
             ctx->persistGrid = std::min(ctx->persistGrid, std::min(ctx->gridMax, d * prop.multiProcessorCount));
             ctx->persistGridConnect = std::min(ctx->persistGridConnect, std::min(ctx->gridMax, d * prop.multiProcessorCount));
+            ctx->tune.leafK = 16;   // contexts sharing the GPU: hold triangle events back until 16 lanes wait on a leaf (+1 % with three lanes, -0.6 % alone)
         }
         if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner,leafK[,blocksPerCU]" (tuning aid)
             int a = 0, b = 0, c = 0, l = 0, d = 0;
