@@ -110,3 +110,23 @@ def test_lanes_are_virtual_ranks_of_the_sample_plan():
         for n in (1, 2, 3):
             parts = rdist.lane_frames(frames, n)
             assert sum(parts) == frames and max(parts) - min(parts) <= 1 and parts == sorted(parts, reverse=True)
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    """`python bench.py --gpus 2` starts its own ranks (no torch.distributed.run around it).  Here there is no GPU, so every rank fails
+    in rt_create ("no HIP device visible: this library has no CPU path") - the launcher must end the other rank, not hang in the
+    rendezvous, and exit non-zero without printing a result line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        import ctypes
+        from magr_ray_tracer_amd import _lib
+        if _lib.device_lib().rt_device_count() > 0:
+            pytest.skip("a GPU is present: the ranks would succeed (covered by test_bench_starts_its_own_ranks_two_on_one_gpu)")
+    except Exception:
+        pass
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "1", "--warmup", "0",
+                        "--width", "64", "--height", "36", "--detail", "0.1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "no HIP device" in r.stderr or "RtError" in r.stderr or "hip" in r.stderr.lower()
