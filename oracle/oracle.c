@@ -15,9 +15,13 @@
  * GPU); here and in the HIP path it is v * (1.0f / sqrtf(d)) with IEEE sqrt and
  * divide, so directions can differ from the reference build in the last 1-2 ulp.
  * Transcendentals (sin, cos, exp, acospi, atan2pi: fisheye camera, sphere lights,
- * sphere textures, dielectrics) come from libm here and are not bit-pinned.
+ * sphere textures, dielectrics) are NOT libm calls: they are the single-precision Cephes
+ * algorithms written out as IEEE + - * / sqrt (orc_expf ... below), the same sequences
+ * the HIP path evaluates, so those scenes are bit-exact HIP vs oracle too; against the
+ * reference's device-library builtins they are a few ulp off (like normalize).
+ * float -> int conversions follow the GPU (NaN -> 0, saturating; f2i_gpu).
  *
- * Build: gcc -O2 -ffp-contract=off -mfma -fopenmp (oracle/Makefile).
+ * Build: gcc -O2 -ffp-contract=off -mfma -fopenmp (magr_ray_tracer_amd/build.py build_oracle).
  */
 #include "oracle.h"
 #include <float.h>
