@@ -406,6 +406,9 @@ RT_FORCEINLINE void test_tri_packed(const DevScene& sc, uint32_t slot, TRay& r)
 {
     const float4* rec = sc.triRecs + (size_t)slot * 3;
     const float4 a = rec[0], b = rec[1], c = rec[2];
+    // Keep the three loads of the record together: left alone, the compiler fetches the flag word first, waits, branches on it and only
+    // then fetches the vertices - two dependent round trips per triangle instead of one.
+    asm volatile("" : : "v"(a.x), "v"(b.x), "v"(c.x));
     const int idx = __float_as_int(c.y);
     if (__float_as_int(c.z) != 0) { test_prim(sc, idx, r); return; } // not a plain triangle: reference-layout test
     const float4 O = mk4(r.ox, r.oy, r.oz, 0.0f), D = mk4(r.dx, r.dy, r.dz, 0.0f);
