@@ -1082,12 +1082,25 @@ RT_FORCEINLINE float4 prim_normal(const RtPrimitive* p, float4 I) // primitives.
 RT_FORCEINLINE int f2i_gpu(float x) { return x != x ? 0 : (x >= 2147483648.0f ? 2147483647 : (x <= -2147483648.0f ? (int)(-2147483647 - 1) : (int)x)); }
 RT_FORCEINLINE uint32_t f2u_gpu(float x) { return !(x > 0.0f) ? 0u : (x >= 4294967296.0f ? 0xffffffffu : (uint32_t)x); }
 RT_FORCEINLINE float4 texel(const DevScene& sc, long long i) { return i >= 0 && i < (long long)sc.nTex ? sc.tex[i] : splat(0.0f); }
-RT_FORCEINLINE float4 albedo_of(const DevScene& sc, const RtPrimitive* prim, const RtMaterial* mat, const SRay& ray) // primitives.cl:107-148
+// The scalar fields of a Material (bytes 32..63: specular, n1, n2, isDielectric | texIdx, texW, texH, isLight) fetched as two 16-byte
+// loads kept together; read field by field where they are used, the compiler turns them into a chain of up to eight dependent fetches.
+struct MatCtl { float specular, n1, n2; uint32_t isDielectric; int32_t texIdx, texW, texH; uint32_t isLight; };
+RT_FORCEINLINE MatCtl load_mat_ctl(const RtMaterial* mat)
+{
+    const uint4* p = reinterpret_cast<const uint4*>(mat);
+    const uint4 a = p[2], b = p[3];
+    asm volatile("" : : "v"(a.x), "v"(b.x));
+    MatCtl m;
+    m.specular = __uint_as_float(a.x); m.n1 = __uint_as_float(a.y); m.n2 = __uint_as_float(a.z); m.isDielectric = a.w & 0xffu;
+    m.texIdx = (int32_t)b.x; m.texW = (int32_t)b.y; m.texH = (int32_t)b.z; m.isLight = b.w & 0xffu;
+    return m;
+}
+RT_FORCEINLINE float4 albedo_of(const DevScene& sc, const RtPrimitive* prim, const RtMaterial* mat, const MatCtl& mc, const SRay& ray) // primitives.cl:107-148
 {
     float4 albedo = ld4(mat->color);
-    const int texIdx = mat->texIdx;
+    const int texIdx = mc.texIdx;
     if (texIdx != -1) {
-        const int texW = mat->texW, texH = mat->texH, type = prim->objType;
+        const int texW = mc.texW, texH = mc.texH, type = prim->objType;
         if (type == RT_PRIM_TRIANGLE) {
             const RtTriangle* t = &prim->obj.triangle;
             float w2 = 1 - ray.u - ray.v;
@@ -1156,12 +1169,12 @@ RT_FORCEINLINE ExtRay transmit_ray(const SRay& ray, float4 T) // ray.cl:31-39
     e.D = T; e.inten = ray.inten; e.bounces = ray.bounces + 1; e.inside = !ray.inside; e.lastSpec = false; e.valid = true;
     return e;
 }
-RT_FORCEINLINE float fresnel(SRay& ray, const RtMaterial* mat, float4& outT) // glass.cl:4-49
+RT_FORCEINLINE float fresnel(SRay& ray, const RtMaterial* mat, const MatCtl& mc, float4& outT) // glass.cl:4-49
 {
     float costhetai = dot4(ray.N, muls(ray.D, -1.0f));
-    float n1 = mat->n1, n2 = mat->n2;
+    float n1 = mc.n1, n2 = mc.n2;
     if (ray.inside) {
-        n1 = mat->n2; n2 = mat->n1;
+        n1 = mc.n2; n2 = mc.n1;
         ray.inten.x *= rt_expf(-mat->absorption.x * ray.t);
         ray.inten.y *= rt_expf(-mat->absorption.y * ray.t);
         ray.inten.z *= rt_expf(-mat->absorption.z * ray.t);
@@ -1175,7 +1188,7 @@ RT_FORCEINLINE float fresnel(SRay& ray, const RtMaterial* mat, float4& outT) // 
     float frac1 = (n1ci - n2ct) / (n1ci + n2ct);
     float frac2 = (n1ct - n2ci) / (n1ct + n2ci);
     float Fr = 0.5f * (frac1 * frac1 + frac2 * frac2);
-    return mat->specular + (1 - mat->specular) * Fr;
+    return mc.specular + (1 - mc.specular) * Fr;
 }
 RT_FORCEINLINE float4 firefly(int on, float4 c) // wavefront.cl:125-127,196-198
 {
@@ -1192,21 +1205,22 @@ RT_FORCEINLINE float4 shade_hit(const DevScene& sc, const DevVariant& var, SRay&
 {
     const RtPrimitive* prim = sc.prims + ray.prim;
     const RtMaterial* mat = sc.mats + ray.matIdx;
-    if (mat->isLight) {
+    const MatCtl mc = load_mat_ctl(mat);
+    if (mc.isLight) {
         if (NEE && !ray.lastSpec) return splat(0.0f);
         return mul4(ray.inten, ld4(mat->emittance));
     }
     const float rnd = rnd_float(seed);
-    if (mat->isDielectric) {
+    if (mc.isDielectric) {
         float4 T = splat(0.0f);
-        float Fr = fresnel(ray, mat, T);
+        float Fr = fresnel(ray, mat, mc, T);
         ext = rnd < Fr ? reflect_ray(ray) : transmit_ray(ray, T);
         if (NEE) ext.lastSpec = true;
-    } else if (rnd < mat->specular) {
+    } else if (rnd < mc.specular) {
         ext = reflect_ray(ray);
         if (NEE) ext.lastSpec = true;
     } else {
-        const float4 albedo = albedo_of(sc, prim, mat, ray);
+        const float4 albedo = albedo_of(sc, prim, mat, mc, ray);
         const float4 BRDF = muls(albedo, kInvPi);
         if (NEE && sc.nLights > 0) {
             uint32_t li = f2u_gpu(floorf(rnd_abs(seed) * (float)sc.nLights));
@@ -1406,6 +1420,7 @@ __global__ __launch_bounds__(kTile, 4) void k_shade(DevScene sc, DevQueues q, De
                 // normal and material id from the dense 16-byte shading record (4 MB for 265k primitives: L2-resident) instead
                 // of two fields 68 bytes apart in the 128-byte Primitive (34 MB); spheres need the hit point: reference layout
                 const float4 rec = sc.shadeRecs[ray.prim];
+                asm volatile("" : : "v"(rec.x), "v"(rec.w));   // one 16-byte fetch, not the tag word first and the normal after the branch on it
                 const uint32_t tag = __float_as_uint(rec.w);
                 ray.matIdx = (int)(tag & 0x07ffffffu);
                 ray.N = (tag >> 28) == RT_PRIM_SPHERE ? prim_normal(sc.prims + ray.prim, ray.I)
