@@ -396,6 +396,18 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         }
         rc = upload(ctx, &sc.shadeRecs, recs.data(), recs.size());
     }
+    if (rc == RT_OK) { // light records (k_shade, NEE): the first 64 bytes of the light's Primitive, {objType, area}, its material's emittance
+        std::vector<float4> lr(std::max<size_t>((size_t)nLights, 1) * 8, make_float4(0, 0, 0, 0));
+        for (int32_t i = 0; i < nLights; i++) {
+            const RtPrimitive& p = prims[lights[i]];
+            memcpy(&lr[(size_t)i * 8], &p.obj, 64);
+            float t; int32_t ty = p.objType; memcpy(&t, &ty, 4);
+            lr[(size_t)i * 8 + 4] = make_float4(t, p.area, 0, 0);
+            const RtFloat4& e = mats[p.matIdx].emittance;
+            lr[(size_t)i * 8 + 5] = make_float4(e.x, e.y, e.z, e.w);
+        }
+        rc = upload(ctx, &sc.lightRecs, lr.data(), lr.size());
+    }
     // Derived layout 1 (rt355_kernels.h, traverse_bvh2_packed): only for BVH2, when the encodings fit.
     ctx->layout = 0;
     if (rc == RT_OK && ctx->cfg.accel == RT_ACCEL_BVH2 && ctx->cfg.extend_variant != 1 && nIdx < (1 << 24)) {

@@ -52,6 +52,7 @@ struct DevScene {
     const float4*        triRecs;    // [nIdx][3]    leaf-ordered triangle vertices + primitive id
     const uint32_t*      rootEntry;  // [nBlas]      encoded root of every instance
     const float4*        shadeRecs;  // [nPrims]     {N.xyz, bits(matIdx | (N.w is -0) << 27 | objType << 28)}: what shade() needs of a 128-B Primitive, in 16 B
+    const float4*        lightRecs;  // [nLights][8]  what NEE needs of light li in one place: objData[0..63], {objType, area}, emittance of its material
     const float4*        quads;      // [nNodes][8]  layout 1 of the BVH4: four child boxes + four encoded child entries (128 B)
     int32_t nLights, nPrims, nBlas, nTex;
 };
@@ -1225,11 +1226,29 @@ RT_FORCEINLINE float4 shade_hit(const DevScene& sc, const DevVariant& var, SRay&
         if (NEE && sc.nLights > 0) {
             uint32_t li = f2u_gpu(floorf(rnd_abs(seed) * (float)sc.nLights));
             if (li >= (uint32_t)sc.nLights) li = (uint32_t)sc.nLights - 1; // reference reads out of bounds here (draw == 1.0)
-            const uint32_t lightIdx = sc.lights[li];
-            const RtPrimitive* lp = sc.prims + lightIdx;
-            float4 pl = random_point_on(lp, seed);
+            // One round trip for everything NEE reads of the light (round 1 walked lights[li] -> Primitive.objType -> vertices -> normal ->
+            // matIdx / area -> Material.emittance: six dependent fetches); same arithmetic as getRandomPoint / getNormal (primitives.cl:91-189).
+            const float4* LR = sc.lightRecs + (size_t)li * 8;
+            const float4 l0 = LR[0], l1 = LR[1], l2 = LR[2], l3 = LR[3], l4 = LR[4], l5 = LR[5];
+            asm volatile("" : : "v"(l0.x), "v"(l1.x), "v"(l2.x), "v"(l3.x), "v"(l4.x), "v"(l5.x));
+            const int ltype = __float_as_int(l4.x);
+            const float larea = l4.y;
+            float4 pl, Nl;
+            if (ltype == RT_PRIM_SPHERE) {            // Sphere { pos; r, r2, invr }
+                float theta = rnd_abs(seed) * 2.0f * kPi;
+                float u = rnd_abs(seed) * 2.0f - 1.0f;
+                float pre = sqrtf(1 - u * u);
+                float x = rt_cosf(theta) * pre, y = rt_sinf(theta) * pre;
+                pl = add4(muls(mk4(x, y, u, 0.0f), l1.x), l0);
+                Nl = muls(sub4(pl, l0), l1.z);
+            } else {                                  // Triangle { v0, v1, v2, N } (a plane light samples like the reference: as a triangle)
+                float u1 = rnd_abs(seed), u2 = rnd_abs(seed);
+                if (u1 + u2 > 1) { u1 = 1 - u1; u2 = 1 - u2; }
+                float4 a = sub4(l1, l0), b = sub4(l2, l0);
+                pl = add4(add4(l0, muls(a, u1)), muls(b, u2));
+                Nl = ltype == RT_PRIM_PLANE ? l0 : l3;
+            }
             float4 dirToLight = sub4(pl, ray.I);
-            float4 Nl = prim_normal(lp, pl);
             float dist = length4(dirToLight);
             float4 L = muls(dirToLight, 1 / dist);
             float dotNL = dot4(ray.N, L);
@@ -1237,8 +1256,8 @@ RT_FORCEINLINE float4 shade_hit(const DevScene& sc, const DevVariant& var, SRay&
                 // The shadow ray carries what connect() needs (wavefront.cl:175-199): its
                 // origin/direction/t_max and the radiance it adds when unoccluded.
                 float4 sInt = muls(ray.inten, (float)sc.nLights);
-                float solidAngle = dot4(Nl, neg4(L)) * lp->area * (1 / (dist * dist));
-                float4 lightColor = ld4(sc.mats[lp->matIdx].emittance);
+                float solidAngle = dot4(Nl, neg4(L)) * larea * (1 / (dist * dist));
+                float4 lightColor = l5;
                 float4 Ld = muls(mul4(muls(lightColor, solidAngle), BRDF), dotNL);
                 float4 color = firefly(var.fireflies, mul4(Ld, sInt));
                 float4 so = add4(ray.I, muls(L, kEps));
