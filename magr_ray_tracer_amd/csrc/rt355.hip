@@ -513,6 +513,33 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
             if (rc == RT_OK) ctx->layout = 1;
         }
     }
+    if (rc == RT_OK) { // derived TLAS records and instance records (traverse_tlas / traverse_instance)
+        auto f2u = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+        auto enc = [&](uint32_t n) { return tlas[n].leftRight == 0 ? (0x80000000u | tlas[n].BLASidx) : n; };
+        std::vector<float4> tp((size_t)nTlas * 4, make_float4(0, 0, 0, 0));
+        for (int32_t i = 0; i < nTlas; i++) {
+            const uint32_t lr = tlas[i].leftRight;
+            if (lr == 0) continue;
+            const RtTLASNode& a = tlas[lr & 0xffffu]; const RtTLASNode& b = tlas[lr >> 16];
+            tp[(size_t)i * 4 + 0] = make_float4(a.aabbMin.x, a.aabbMin.y, a.aabbMin.z, a.aabbMax.x);
+            tp[(size_t)i * 4 + 1] = make_float4(a.aabbMax.y, a.aabbMax.z, b.aabbMin.x, b.aabbMin.y);
+            tp[(size_t)i * 4 + 2] = make_float4(b.aabbMin.z, b.aabbMax.x, b.aabbMax.y, b.aabbMax.z);
+            tp[(size_t)i * 4 + 3] = make_float4(f2u(enc(lr & 0xffffu)), f2u(enc(lr >> 16)), 0, 0);
+        }
+        std::vector<uint32_t> roots((size_t)nBlas, 0u);
+        if (ctx->layout == 1) HIPCHK(hipMemcpy(roots.data(), sc.rootEntry, sizeof(uint32_t) * (size_t)nBlas, hipMemcpyDeviceToHost));
+        std::vector<float4> ir((size_t)nBlas * 4);
+        for (int32_t b = 0; b < nBlas; b++) {
+            const float* T = blas[b].invT;
+            ir[(size_t)b * 4 + 0] = make_float4(T[0], T[1], T[2], T[3]);
+            ir[(size_t)b * 4 + 1] = make_float4(T[4], T[5], T[6], T[7]);
+            ir[(size_t)b * 4 + 2] = make_float4(T[8], T[9], T[10], T[11]);
+            ir[(size_t)b * 4 + 3] = make_float4(f2u(roots[(size_t)b]), f2u(blas[b].bvhIdx), 0, 0);
+        }
+        rc = upload(ctx, &sc.tlasPairs, tp.data(), tp.size());
+        if (rc == RT_OK) rc = upload(ctx, &sc.instRecs, ir.data(), ir.size());
+        sc.tlasRoot = enc(0);
+    }
     if (rc != RT_OK) { free_bag(ctx->sceneAllocs); ctx->sceneLoaded = false; return rc; }
     sc.nLights = nLights; sc.nPrims = nPrims; sc.nBlas = nBlas; sc.nTex = nTexels;
     // persistent-wavefront traversal: layout 1 and a TLAS whose root is a leaf (one BLAS)

@@ -52,6 +52,9 @@ struct DevScene {
     const float4*        triRecs;    // [nIdx][3]    leaf-ordered triangle vertices + primitive id
     const uint32_t*      rootEntry;  // [nBlas]      encoded root of every instance
     const float4*        shadeRecs;  // [nPrims]     {N.xyz, bits(matIdx | (N.w is -0) << 27 | objType << 28)}: what shade() needs of a 128-B Primitive, in 16 B
+    const float4*        tlasPairs;  // [nTlas][4]    TLAS interior node i: both child boxes + encoded children (leaf: kLeafBit | BLASidx), one 64-B fetch
+    const float4*        instRecs;   // [nBlas][4]    rows 0..2 of invT + {encoded BLAS root (layout 1), bvhIdx}: one 64-B fetch per instance visit
+    uint32_t             tlasRoot;   // encoded TLAS root (a leaf when the scene has one BLAS)
     const float4*        lightRecs;  // [nLights][8]  what NEE needs of light li in one place: objData[0..63], {objType, area}, emittance of its material
     const float4*        quads;      // [nNodes][8]  layout 1 of the BVH4: four child boxes + four encoded child entries (128 B)
     int32_t nLights, nPrims, nBlas, nTex;
@@ -604,57 +607,64 @@ RT_FORCEINLINE int traverse_bvh4_packed(const DevScene& sc, TRay& r, uint32_t ro
     return steps;
 }
 
-// instanceIntersect, tlas.cl:9-26 with transformRay :3-8 and util.cl:61-87.
+// instanceIntersect, tlas.cl:9-26 with transformRay :3-8 and util.cl:61-87.  The instance record (rows 0..2 of invT + the encoded BLAS
+// root) is one 64-byte fetch; round 1 read BVHInstance.invT and rootEntry[] separately.
 template <int ACCEL, int LAYOUT, bool OCC>
-RT_FORCEINLINE int traverse_instance(const DevScene& sc, TRay& r, const RtBVHInstance* inst, uint32_t instIdx, uint32_t* stk, WorkCtr& wc)
+RT_FORCEINLINE int traverse_instance(const DevScene& sc, TRay& r, uint32_t instIdx, uint32_t* stk, WorkCtr& wc)
 {
-    const float* T = inst->invT;
+    const float4* ir = sc.instRecs + (size_t)instIdx * 4;
+    const float4 t0 = ir[0], t1 = ir[1], t2 = ir[2], t3 = ir[3];
     const float bx = r.ox, by = r.oy, bz = r.oz, bdx = r.dx, bdy = r.dy, bdz = r.dz, brx = r.rx, bry = r.ry, brz = r.rz;
     const float4 Dv = mk4(bdx, bdy, bdz, 0.0f), Ov = mk4(bx, by, bz, 0.0f);
-    r.dx = dot3(mk4(T[0], T[1], T[2], 0), Dv); r.dy = dot3(mk4(T[4], T[5], T[6], 0), Dv); r.dz = dot3(mk4(T[8], T[9], T[10], 0), Dv);
-    r.ox = dot3(mk4(T[0], T[1], T[2], 0), Ov) + T[3]; r.oy = dot3(mk4(T[4], T[5], T[6], 0), Ov) + T[7];
-    r.oz = dot3(mk4(T[8], T[9], T[10], 0), Ov) + T[11];
+    r.dx = dot3(mk4(t0.x, t0.y, t0.z, 0), Dv); r.dy = dot3(mk4(t1.x, t1.y, t1.z, 0), Dv); r.dz = dot3(mk4(t2.x, t2.y, t2.z, 0), Dv);
+    r.ox = dot3(mk4(t0.x, t0.y, t0.z, 0), Ov) + t0.w; r.oy = dot3(mk4(t1.x, t1.y, t1.z, 0), Ov) + t1.w;
+    r.oz = dot3(mk4(t2.x, t2.y, t2.z, 0), Ov) + t2.w;
     r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
     wc.inst++;
+    const uint32_t rootEnc = __float_as_uint(t3.x), bvhIdx = __float_as_uint(t3.y);
     int steps;
-    if (ACCEL == RT_ACCEL_BVH4) steps = LAYOUT == 1 ? traverse_bvh4_packed<OCC>(sc, r, sc.rootEntry[instIdx], stk, wc) : traverse_bvh4<OCC>(sc, r, inst->bvhIdx, stk, wc);
-    else if (LAYOUT == 1) steps = traverse_bvh2_packed<OCC>(sc, r, sc.rootEntry[instIdx], stk, wc);
-    else steps = traverse_bvh2<OCC>(sc, r, inst->bvhIdx, stk, wc);
+    if (ACCEL == RT_ACCEL_BVH4) steps = LAYOUT == 1 ? traverse_bvh4_packed<OCC>(sc, r, rootEnc, stk, wc) : traverse_bvh4<OCC>(sc, r, bvhIdx, stk, wc);
+    else if (LAYOUT == 1) steps = traverse_bvh2_packed<OCC>(sc, r, rootEnc, stk, wc);
+    else steps = traverse_bvh2<OCC>(sc, r, bvhIdx, stk, wc);
     r.ox = bx; r.oy = by; r.oz = bz; r.dx = bdx; r.dy = bdy; r.dz = bdz; r.rx = brx; r.ry = bry; r.rz = brz;
     return steps;
 }
 
-// intersectTLAS, tlas.cl:28-77.  The TLAS stack (<= 32 entries of 16-bit ids) is a
-// private array; with a single BLAS the root is a leaf and it is never touched.
+// intersectTLAS, tlas.cl:28-77, over the derived TLAS records: an interior visit is ONE fetch (both child boxes and both encoded
+// children; the reference array costs the node's leftRight word, then the two child nodes), a leaf costs none (its BLAS index sits in
+// the parent's record).  Visit order, pruning and counters are the reference's.  The TLAS stack (<= 32 entries) is a private array;
+// with a single BLAS the root is a leaf and it is never touched.
 template <int ACCEL, int LAYOUT, bool OCC>
 RT_FORCEINLINE int traverse_tlas(const DevScene& sc, TRay& r, uint32_t* stk, WorkCtr& wc)
 {
-    const RtTLASNode* tl = sc.tlas;
-    uint16_t tstack[RT_TLAS_STACK];
-    uint32_t node = 0, sp = 0;
+    uint16_t tstack[RT_TLAS_STACK];   // 16-bit entries as in the reference (bit 15 = leaf; <= 256 instances, <= 512 nodes)
+    uint32_t cur = sc.tlasRoot, sp = 0;
+    auto pack16 = [](uint32_t c) { return (uint16_t)((c >> 16) | (c & 0x7fffu)); };
+    auto unpack16 = [](uint32_t v) { return ((v & 0x8000u) << 16) | (v & 0x7fffu); };
     int steps = 0;
     const float tLight = r.t;
     for (;;) {
-        const uint2 lr = *reinterpret_cast<const uint2*>(&tl[node].leftRight);
-        if (lr.x == 0) {
-            int value = traverse_instance<ACCEL, LAYOUT, OCC>(sc, r, sc.blas + lr.y, lr.y, stk, wc);
+        if (cur & kLeafBit) {
+            int value = traverse_instance<ACCEL, LAYOUT, OCC>(sc, r, cur & 0x7fffffffu, stk, wc);
             if (OCC && value == -1) return -1;
             steps += value;
             if (sp == 0) break;
-            node = tstack[--sp];
+            cur = unpack16(tstack[--sp]);
             continue;
         }
         wc.tlas++;
-        uint32_t c1 = lr.x & 0xffffu, c2 = lr.x >> 16;
-        float d1 = slab(r, ld4(tl[c1].aabbMin), ld4(tl[c1].aabbMax));
-        float d2 = slab(r, ld4(tl[c2].aabbMin), ld4(tl[c2].aabbMax));
+        const float4* p = sc.tlasPairs + (size_t)cur * 4;
+        const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        float d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
+        float d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
+        uint32_t c1 = __float_as_uint(q3.x), c2 = __float_as_uint(q3.y);
         if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t c = c1; c1 = c2; c2 = c; }
         if (d1 >= tLight) {
             if (sp == 0) break;
-            node = tstack[--sp];
+            cur = unpack16(tstack[--sp]);
         } else {
-            node = c1;
-            if (d2 < tLight) tstack[sp++] = (uint16_t)c2;
+            cur = c1;
+            if (d2 < tLight) tstack[sp++] = pack16(c2);
         }
     }
     return steps;
