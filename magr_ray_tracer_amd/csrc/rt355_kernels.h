@@ -580,6 +580,7 @@ RT_FORCEINLINE int traverse_bvh4_packed(const DevScene& sc, TRay& r, uint32_t ro
         steps++; wc.node++;
         const float4* p = sc.quads + (size_t)node * 8;
         const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5], q6 = p[6];
+        asm volatile("" : : "v"(q0.x), "v"(q1.x), "v"(q2.x), "v"(q3.x), "v"(q4.x), "v"(q5.x), "v"(q6.x));   // one round trip (see test_tri_packed)
         const uint32_t e[4] = { __float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w) };
         float dist[4];
         dist[0] = e[0] != kNoChild ? slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f)) : kFar;
@@ -1051,6 +1052,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist4(DevScene sc, DevQueue
                 steps++; wc.node++;
                 const float4* p = sc.quads + (size_t)cur * 8;
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5], q6 = p[6];
+                asm volatile("" : : "v"(q0.x), "v"(q1.x), "v"(q2.x), "v"(q3.x), "v"(q4.x), "v"(q5.x), "v"(q6.x));   // one round trip (see test_tri_packed)
                 e0 = __float_as_uint(q6.x); e1 = __float_as_uint(q6.y); e2 = __float_as_uint(q6.z); e3 = __float_as_uint(q6.w);
                 const float d0 = e0 != kNoChild ? slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f)) : kFar;
                 const float d1 = e1 != kNoChild ? slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f)) : kFar;
