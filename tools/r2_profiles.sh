@@ -6,7 +6,7 @@ python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --lanes 1 --no-cpu-baseline > $O/bench_lanes1.json 2> $O/bench_lanes1.err
 python bench.py --accel bvh4 --no-cpu-baseline > $O/bench_bvh4.json 2> $O/bench_bvh4.err
 python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench_driver_flags.err
-bash tools/trace_default.sh r2_final/trace_default
+bash tools/trace_default.sh r2_final/trace_default --no-single
 bash tools/trace.sh r2_final/trace_lanes1 --lanes 1
 python tools/config_table.py > $O/config_table.log 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/gather_probe.hip -o /tmp/gather_probe.bin && for n in 8 12 14 16 17 19 21; do /tmp/gather_probe.bin $n; done > $O/gather_probe.log 2>&1
