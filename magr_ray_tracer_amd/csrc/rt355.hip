@@ -57,6 +57,7 @@ struct RtCtx {
     PersistTune tune{ 112, 24, 6, 8 }, tuneConnect{ 128, 32, 6, 16 }, tune4{ 64, 20, 6, 8 };   // extend (BVH2), connect, extend (BVH4): measured optima (tools/tune_extend.sh, tune_connect.sh, tune_persist.sh)
     float4* dPostF = nullptr; uchar4* dPostB = nullptr;   // post-processing outputs (lazy)
     int32_t* dSteps = nullptr;   // per-ray `steps` buffer, only bound while rt_debug_enable_steps is on
+    int shadeTile = kTile;  // k_shade tile = workgroup size: kTile (512), or 256 for contexts that share the GPU (RtConfig.shade_blocks_per_cu > 0)
     int shadeGrid = 1024;   // workgroups of k_shade (what the CUs hold at once; the kernel does not depend on it); set in rt_create
 };
 enum { ST_GENERATE, ST_EXTEND, ST_SHADE, ST_COMPACT, ST_CONNECT, ST_ACCUM };
@@ -183,8 +184,15 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
         // (MI355X_MICROARCH.md, residency) = 6 for any kernel (<= 112 SGPRs), 7 up to 96 SGPRs.  k_shade: 2 workgroups of 512 threads (registers, 78 KB LDS).
         hipDeviceProp_t prop; int perCU = 0;
         HIPCHK(hipGetDeviceProperties(&prop, c.device));
-        if (c.shading == RT_SHADING_NEE) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<true>, kTile, 0));
-        else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_shade<false>, kTile, 0));
+        ctx->shadeTile = c.shade_blocks_per_cu > 0 ? 256 : kTile;
+        if (const char* t = getenv("RT355_SHADE_TILE")) { const int v = atoi(t); if (v == 256 || v == 512) ctx->shadeTile = v; }
+        if (c.shading == RT_SHADING_NEE) {
+            if (ctx->shadeTile == 256) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_shade<true, 256>), 256, 0));
+            else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_shade<true, kTile>), kTile, 0));
+        } else {
+            if (ctx->shadeTile == 256) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_shade<false, 256>), 256, 0));
+            else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_shade<false, kTile>), kTile, 0));
+        }
         perCU = std::min(perCU, kAdmitAnySgpr);
         ctx->shadeGrid = prop.multiProcessorCount * std::max(1, perCU);
         if (c.shade_blocks_per_cu > 0 && c.shade_blocks_per_cu <= 16) ctx->shadeGrid = prop.multiProcessorCount * c.shade_blocks_per_cu;
@@ -715,11 +723,15 @@ extern "C" int rt_stage_shade(RtCtx* ctx, int32_t bounce)
         HIPCHK(hipMemsetAsync(ctx->q.supAcc[bounce & 1], 0, sizeof(unsigned long long) * (nTiles / 64 + 2), ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->q.shadeTicket + (size_t)bounce * kTicketClasses * kTicketStride, 0, sizeof(int32_t) * (size_t)kTicketClasses * kTicketStride, ctx->stream));
     }
-    const dim3 sg((unsigned)std::max(1, std::min(ctx->shadeGrid, (ctx->nPix + kTile - 1) / kTile)));
-    if (ctx->cfg.shading == RT_SHADING_NEE)
-        LAUNCHB(ctx, ST_SHADE, k_shade<true>, sg, kTile, 0, ctx->sc, ctx->q, ctx->var, bounce);
-    else
-        LAUNCHB(ctx, ST_SHADE, k_shade<false>, sg, kTile, 0, ctx->sc, ctx->q, ctx->var, bounce);
+    const int tileSz = ctx->shadeTile;
+    const dim3 sg((unsigned)std::max(1, std::min(ctx->shadeGrid, (ctx->nPix + tileSz - 1) / tileSz)));
+    if (ctx->cfg.shading == RT_SHADING_NEE) {
+        if (tileSz == 256) LAUNCHB(ctx, ST_SHADE, (k_shade<true, 256>), sg, 256, 0, ctx->sc, ctx->q, ctx->var, bounce);
+        else LAUNCHB(ctx, ST_SHADE, (k_shade<true, kTile>), sg, kTile, 0, ctx->sc, ctx->q, ctx->var, bounce);
+    } else {
+        if (tileSz == 256) LAUNCHB(ctx, ST_SHADE, (k_shade<false, 256>), sg, 256, 0, ctx->sc, ctx->q, ctx->var, bounce);
+        else LAUNCHB(ctx, ST_SHADE, (k_shade<false, kTile>), sg, kTile, 0, ctx->sc, ctx->q, ctx->var, bounce);
+    }
     ctx->shadeRun[bounce] = true;
     HIPCHK(hipGetLastError());
     return RT_OK;

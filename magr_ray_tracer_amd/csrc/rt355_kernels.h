@@ -1325,15 +1325,18 @@ RT_FORCEINLINE unsigned long long wait_word(const unsigned long long* p, unsigne
     return v;
 }
 
-template <bool NEE>
-__global__ __launch_bounds__(kTile, 4) void k_shade(DevScene sc, DevQueues q, DevVariant var, int bounce)
+// TILE = queue slots per tile = threads of the workgroup: 512 for a context that has the GPU to itself (half the tickets, publishes and
+// drains per ray), 256 for contexts that share it (39 instead of 78 KB of LDS: such a workgroup fits beside the other contexts' traversal
+// workgroups instead of waiting for them to leave the CU: +2 % with three lanes, -4.6 % alone).
+template <bool NEE, int TILE>
+__global__ __launch_bounds__(TILE, 4) void k_shade(DevScene sc, DevQueues q, DevVariant var, int bounce)
 {
     // [2]: a tile's outputs are written one tile late (see the loop), so the counts and the shadow records of two tiles are alive
-    __shared__ uint32_t sWaveE[2][kTile / 64], sWaveS[2][kTile / 64], sBaseE, sBaseS;
+    __shared__ uint32_t sWaveE[2][TILE / 64], sWaveS[2][TILE / 64], sBaseE, sBaseS;
     // Survivors wait in LDS (104 B per lane) while the ordered scan resolves, instead of in ~28 registers: the
     // kernel's occupancy is set by the shading code, not by values that are merely parked across the scan.
-    __shared__ float4 sExtO[kTile], sExtD[kTile], sExtI[kTile], sShA[2][kTile], sShB[2][kTile], sShC[2][kTile];
-    __shared__ uint2 sExtM[kTile];
+    __shared__ float4 sExtO[TILE], sExtD[TILE], sExtI[TILE], sShA[2][TILE], sShB[2][TILE], sShC[2][TILE];
+    __shared__ uint2 sExtM[TILE];
     const int cur = bounce & 1, nxt = cur ^ 1;
     unsigned long long* state = q.tile[cur];
     unsigned long long* const* super = q.super;
@@ -1342,7 +1345,7 @@ __global__ __launch_bounds__(kTile, 4) void k_shade(DevScene sc, DevQueues q, De
         if (blockIdx.x == 0 && threadIdx.x == 0) { q.nRays[bounce + 1] = 0; q.nShadow[bounce + 1] = q.nShadow[bounce]; }
         return;
     }
-    const uint32_t numTiles = (uint32_t)((n + kTile - 1) / kTile);
+    const uint32_t numTiles = (uint32_t)((n + TILE - 1) / TILE);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int shadowBase = q.nShadow[bounce];
 
@@ -1352,7 +1355,7 @@ __global__ __launch_bounds__(kTile, 4) void k_shade(DevScene sc, DevQueues q, De
         if (wave == 0) {
             uint32_t aggE = 0, aggS = 0;
 #pragma unroll
-            for (int w = 0; w < kTile / 64; w++) { aggE += sWaveE[pp][w]; aggS += sWaveS[pp][w]; }
+            for (int w = 0; w < TILE / 64; w++) { aggE += sWaveE[pp][w]; aggS += sWaveS[pp][w]; }
             // Level 1 of the ordered scan: the counts of the earlier tiles of the own super-tile (one 64-lane read) plus the
             // inclusive prefix of the previous super-tile (level 2, resolved by whichever workgroup closed that super-tile).
             const uint32_t sup = t >> 6, inSup = t & 63u;
@@ -1400,7 +1403,7 @@ __global__ __launch_bounds__(kTile, 4) void k_shade(DevScene sc, DevQueues q, De
     // the queue entries of the NEXT tile are fetched before the previous tile is drained, so their latency hides behind the drain
     struct TileIn { float4 hit, O, D, inten; uint2 meta; uint32_t seed; };
     auto fetch = [&](uint32_t t, TileIn& in) {
-        const int j = (int)t * kTile + threadIdx.x;
+        const int j = (int)t * TILE + threadIdx.x;
         if (t < numTiles && j < n) {
             in.hit = q.hit[j]; in.meta = q.meta[cur][j]; in.O = q.O[cur][j]; in.D = q.D[cur][j]; in.inten = q.inten[cur][j]; in.seed = q.seeds[j];
         }
@@ -1421,7 +1424,7 @@ __global__ __launch_bounds__(kTile, 4) void k_shade(DevScene sc, DevQueues q, De
     TileIn in;
     fetch(tile, in);
     for (; tile < numTiles; par ^= 1) {
-        const int i = (int)tile * kTile + threadIdx.x;
+        const int i = (int)tile * TILE + threadIdx.x;
         if (threadIdx.x == 0) {
             q.tile[nxt][1 + tile] = 0ull;     // arm shade(bounce+1)'s scan (its queue is never longer)
             tkNext = (uint32_t)atomicAdd(ticket, 1);
@@ -1479,7 +1482,7 @@ __global__ __launch_bounds__(kTile, 4) void k_shade(DevScene sc, DevQueues q, De
         if (wave == 0) {
             uint32_t aggE = 0, aggS = 0;
 #pragma unroll
-            for (int w = 0; w < kTile / 64; w++) { aggE += sWaveE[par][w]; aggS += sWaveS[par][w]; }
+            for (int w = 0; w < TILE / 64; w++) { aggE += sWaveE[par][w]; aggS += sWaveS[par][w]; }
             const uint32_t sup = tile >> 6;
             unsigned long long acc = 0ull;
             if (lane == 0) {
