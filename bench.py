@@ -137,7 +137,7 @@ def main():
         for p in rdist.plans(args.shard, W, H, rank, world, m, lanes):
             d = Device(W, H, y0=p["y0"], y1=p["y1"], accel=accel, device=local, profile=0 if args.no_profile else 1,
                        extend_variant=args.extend_variant, shade_blocks_per_cu=1 if lanes > 1 else 0,      # several streams share the GPU:
-                       persist_blocks_per_cu=6 if lanes > 1 else 0)                                            # leave each other room
+                       persist_blocks_per_cu=4 if lanes > 1 else 0)                                            # leave each other room
             d.upload(sa)
             d.bind_accum(accums[m])
             seeds = np.zeros(p["seed_count"], np.uint32)
