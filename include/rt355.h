@@ -54,9 +54,10 @@ typedef struct RtConfig {
     int32_t profile;            /* HIP-event brackets on the context's stream: 0 none, 1 extend launches only
                                  * (what the roofline needs; ~1 % overhead), 2 every stage launch (~3.5 %)        */
     int32_t shade_blocks_per_cu;/* k_shade workgroups per CU: 0 = what the CUs hold (2, best for one context with the GPU to itself);
-                                 * 1 leaves room for the kernels of other contexts (best when several sample streams share the GPU) */
+                                 * > 0 also selects 256-slot tiles (39 KB of LDS instead of 78): 1 leaves room for the kernels of
+                                 * other contexts (best when several sample streams share the GPU)                               */
     int32_t persist_blocks_per_cu; /* workgroups per CU of the persistent traversal grids: 0 = what the hardware admits (7 extend / 6 connect);
-                                 * 6 is ~1 % faster when three contexts share the GPU */
+                                 * 4 is best when three contexts share the GPU (their workgroups then fit beside each other)      */
     int32_t reserved[1];
 } RtConfig;
 
