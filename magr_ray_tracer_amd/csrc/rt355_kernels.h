@@ -784,6 +784,44 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int
 // launch does not start with thousands of waves hammering one counter); further chunks are dequeued.
 struct PersistTune { int chunk, refill, inner, leafK; };   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path
 
+// Short queue (late bounces, and bounce 0 when it is launched with one workgroup per 256 rays): every wave gets at most one 64-ray chunk
+// and nothing is left to refill from, so run the plain one-ray-per-lane loop, which has less per-step overhead than the refill machine.
+template <bool OCC, bool COH>
+RT_FORCEINLINE void trace_short_queue(const DevScene& sc, const DevQueues& q, int b0, int qFirst, int n, int renderBVH, const float* T,
+                                      uint32_t rootEntry, uint32_t* stk, int waveId, int lane)
+{
+    WorkCtr wc = { 0, 0, 0, 0 };
+    uint32_t rays = 0;
+    TRay r; r.t = 0; r.prim = -1; r.u = r.v = 0; r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.rx = r.ry = r.rz = 0;
+    int idx = waveId * 64 + lane;
+    if (!OCC && b0 == 0 && ((q.width | (q.nPix / q.width)) & 7) == 0) {
+        // primary rays: a wave takes an 8x8 pixel tile instead of a 64x1 strip (the queue of bounce 0 is the pixel grid)
+        const int tilesX = q.width >> 3, ty = waveId / tilesX, tx = waveId - ty * tilesX;
+        idx = ((ty << 3) + (lane >> 3)) * q.width + (tx << 3) + (lane & 7);
+    }
+    if (idx < n) {
+        float4 O, D; float tmax;
+        if (OCC) { const float4 a = q.sA[qFirst + idx], b = q.sB[qFirst + idx]; O = a; D = b; tmax = a.w; }
+        else { O = q.O[b0 & 1][idx]; D = q.D[b0 & 1][idx]; tmax = kFar; }
+        const float4 Dv = mk4(D.x, D.y, D.z, 0.0f), Ov = mk4(O.x, O.y, O.z, 0.0f);
+        r.dx = dot3(mk4(T[0], T[1], T[2], 0), Dv); r.dy = dot3(mk4(T[4], T[5], T[6], 0), Dv); r.dz = dot3(mk4(T[8], T[9], T[10], 0), Dv);
+        r.ox = dot3(mk4(T[0], T[1], T[2], 0), Ov) + T[3]; r.oy = dot3(mk4(T[4], T[5], T[6], 0), Ov) + T[7];
+        r.oz = dot3(mk4(T[8], T[9], T[10], 0), Ov) + T[11];
+        r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
+        r.t = tmax; r.prim = -1; r.u = 0.0f; r.v = 0.0f;
+        rays = 1; wc.inst = 1;
+        const int st = COH ? traverse_bvh2_packed_coherent(sc, r, rootEntry, stk, wc) : traverse_bvh2_packed<OCC>(sc, r, rootEntry, stk, wc);
+        if (OCC) { if (st == -1) q.sC[qFirst + idx] = splat(0.0f); }
+        else {
+            q.hit[idx] = mk4(r.t, __int_as_float(r.prim), r.u, r.v);
+            if (q.steps) q.steps[idx] = st;
+            if (renderBVH) q.accum[q.firstPixel + idx] = splat((float)(uint32_t)st / 255.f);
+        }
+    }
+    flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
+}
+
+
 template <bool OCC, bool COH = false>
 __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues q, int b0, int b1, int renderBVH, PersistTune tune)
 {
@@ -807,37 +845,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
     int slot = -1, steps = 0;
     float tLight = 0;
     const int nWaves = gridDim.x * (kBlock / 64), waveId = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (n <= nWaves * 64) {
-        // Short queue (late bounces): every wave gets at most one 64-ray chunk and nothing is left to refill from, so
-        // run the plain one-ray-per-lane loop, which has less per-step overhead than the refill state machine.
-        int idx = waveId * 64 + lane;
-        if (!OCC && b0 == 0 && ((q.width | (q.nPix / q.width)) & 7) == 0) {
-            // primary rays: a wave takes an 8x8 pixel tile instead of a 64x1 strip (the queue of bounce 0 is the pixel grid)
-            const int tilesX = q.width >> 3, ty = waveId / tilesX, tx = waveId - ty * tilesX;
-            idx = ((ty << 3) + (lane >> 3)) * q.width + (tx << 3) + (lane & 7);
-        }
-        if (idx < n) {
-            float4 O, D; float tmax;
-            if (OCC) { const float4 a = q.sA[qFirst + idx], b = q.sB[qFirst + idx]; O = a; D = b; tmax = a.w; }
-            else { O = q.O[b0 & 1][idx]; D = q.D[b0 & 1][idx]; tmax = kFar; }
-            const float4 Dv = mk4(D.x, D.y, D.z, 0.0f), Ov = mk4(O.x, O.y, O.z, 0.0f);
-            r.dx = dot3(mk4(T[0], T[1], T[2], 0), Dv); r.dy = dot3(mk4(T[4], T[5], T[6], 0), Dv); r.dz = dot3(mk4(T[8], T[9], T[10], 0), Dv);
-            r.ox = dot3(mk4(T[0], T[1], T[2], 0), Ov) + T[3]; r.oy = dot3(mk4(T[4], T[5], T[6], 0), Ov) + T[7];
-            r.oz = dot3(mk4(T[8], T[9], T[10], 0), Ov) + T[11];
-            r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
-            r.t = tmax; r.prim = -1; r.u = 0.0f; r.v = 0.0f;
-            rays = 1; wc.inst = 1;
-            const int st = COH ? traverse_bvh2_packed_coherent(sc, r, rootEntry, stk, wc) : traverse_bvh2_packed<OCC>(sc, r, rootEntry, stk, wc);
-            if (OCC) { if (st == -1) q.sC[qFirst + idx] = splat(0.0f); }
-            else {
-                q.hit[idx] = mk4(r.t, __int_as_float(r.prim), r.u, r.v);
-                if (q.steps) q.steps[idx] = st;
-                if (renderBVH) q.accum[q.firstPixel + idx] = splat((float)(uint32_t)st / 255.f);
-            }
-        }
-        flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
-        return;
-    }
+    if (n <= nWaves * 64) { trace_short_queue<OCC, COH>(sc, q, b0, qFirst, n, renderBVH, T, rootEntry, stk, waveId, lane); return; }
     int chunkNext = min(waveId * kChunk, n), chunkEnd = min(waveId * kChunk + kChunk, n);   // wave-uniform
     bool exhausted = false;                                                                  // wave-uniform
 

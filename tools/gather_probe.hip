@@ -67,6 +67,32 @@ __global__ __launch_bounds__(256) void gatherB(const float4* __restrict__ tab, i
     out[gid] = acc;
 }
 
+// C: TWO lanes per chain.  The record is laid out as two 32-byte halves (child box + child entry each); the even lane of a pair fetches
+// and tests the first half, the odd lane the second (2 x global_load_dwordx4 per lane, both lanes of a pair in the same 64-B line), and
+// the two results are exchanged by DPP quad_perm [1,0,3,2].  32 chains per wave, half the slab work per lane.
+__device__ __forceinline__ float swap1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); }
+__device__ __forceinline__ uint32_t swap1u(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true); }
+
+__global__ __launch_bounds__(256) void gatherC(const float4* __restrict__ tab2, int steps, float* out, uint32_t mask)
+{
+    extern __shared__ uint32_t pad[];
+    const int tid = blockIdx.x * 256 + threadIdx.x, gid = tid >> 1, half = tid & 1;
+    uint32_t idx = ((uint32_t)gid * 2654435761u >> 13) & mask;
+    float acc = 0, ox = gid * 1e-6f, oy = 0.5f, oz = 0.25f, rx = 1.5f, ry = -0.7f, rz = 0.9f;
+    for (int s = 0; s < steps; s++) {
+        const float4* p = tab2 + (size_t)idx * 4 + half * 2;
+        const float4 q0 = p[0], q1 = p[1];          // (lo.xyz, hi.x) (hi.yz, entry, -)
+        const float a0 = (q0.x - ox) * rx, a1 = (q0.w - ox) * rx, b0 = (q0.y - oy) * ry, b1 = (q1.x - oy) * ry, c0 = (q0.z - oz) * rz, c1 = (q1.y - oz) * rz;
+        const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1)), tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+        const float mine = tf >= tn ? tn : 1e30f, other = swap1(mine);
+        const float w = half ? other - mine : mine - other;
+        acc += w;
+        const uint32_t e = __float_as_uint(q1.z), eo = swap1u(e);
+        idx = (w > 0.0f) == (half == 0) ? e : eo;
+    }
+    if (!half) out[gid] = acc + (float)pad[0] * 0.0f;
+}
+
 int main(int argc, char** argv)
 {
     const int nrec = 1 << (argc > 1 ? atoi(argv[1]) : 19), steps = 64;   // table = nrec * 64 B
@@ -80,7 +106,17 @@ int main(int argc, char** argv)
         uint32_t a = rnd() & (nrec - 1), b = rnd() & (nrec - 1);
         memcpy(&r[12], &a, 4); memcpy(&r[13], &b, 4); r[14] = r[15] = 0;
     }
-    float4* tab; float* out;
+    // layout for C: half 0 = (q0.x q0.y q0.z | q0.w q1.x q1.y -> lo.xyz, hi.xyz), entry a; half 1 likewise from (q1.z q1.w q2.x | q2.y q2.z q2.w), entry b
+    std::vector<float> h2((size_t)nrec * 16);
+    for (int i = 0; i < nrec; i++) {
+        const float* r = &h[(size_t)i * 16]; float* d = &h2[(size_t)i * 16];
+        // A's work(): box 0 uses x: r0,r3  y: r1,r4  z: r2,r5 ; box 1 uses x: r6,r9  y: r7,r10  z: r8,r11
+        d[0] = r[0]; d[1] = r[1]; d[2] = r[2]; d[3] = r[3]; d[4] = r[4]; d[5] = r[5]; d[6] = r[12]; d[7] = 0;
+        d[8] = r[6]; d[9] = r[7]; d[10] = r[8]; d[11] = r[9]; d[12] = r[10]; d[13] = r[11]; d[14] = r[13]; d[15] = 0;
+    }
+    float4* tab; float* out; float4* tab2;
+    CHK(hipMalloc(&tab2, h2.size() * 4)); CHK(hipMemcpy(tab2, h2.data(), h2.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> rc(256 * 256 * 8);
     const int maxThreads = 256 * 256 * 8;
     CHK(hipMalloc(&tab, h.size() * 4)); CHK(hipMalloc(&out, (size_t)maxThreads * 4));
     CHK(hipMemcpy(tab, h.data(), h.size() * 4, hipMemcpyHostToDevice));
@@ -104,6 +140,22 @@ int main(int argc, char** argv)
             CHK(hipMemcpy(which ? rb.data() : ra.data(), out, (size_t)total * 4, hipMemcpyDeviceToHost));
             printf("%s blocks/CU %d (lds %zu KB): %.3f ms, %.2f G records/s\n", which ? "B coop" : "A 4xld", perCU, lds >> 10, best,
                    (double)total * steps / best / 1e6);
+        }
+        {
+            // C with the same number of THREADS (half the chains per launch) and with the same number of CHAINS (twice the workgroups)
+            for (int mult = 1; mult <= 2; mult++) {
+                float best = 1e9f;
+                for (int rep = 0; rep < 5; rep++) {
+                    CHK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(gatherC, dim3(blocks * mult), dim3(256), lds / mult, 0, tab2, steps, out, (uint32_t)(nrec - 1));
+                    CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                    float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+                }
+                const int chains = total * mult / 2;
+                CHK(hipMemcpy(rc.data(), out, (size_t)chains * 4, hipMemcpyDeviceToHost));
+                int badc = 0; for (int i = 0; i < chains && i < total; i++) if (ra[i] != rc[i]) badc++;
+                printf("C pair blocks/CU %d x%d: %.3f ms, %.2f G records/s  mismatches vs A %d\n", perCU, mult, best, (double)chains * steps / best / 1e6, badc);
+            }
         }
         int bad = 0;
         if (lds >= 16 * 1024) for (int i = 0; i < total; i++) if (ra[i] != rb[i]) bad++;
