@@ -93,6 +93,47 @@ __global__ __launch_bounds__(256) void gatherC(const float4* __restrict__ tab2, 
     if (!half) out[gid] = acc + (float)pad[0] * 0.0f;
 }
 
+// D: one chain per lane as in A, but the lanes of a pair fetch TOGETHER: in load group I both lanes read the record of the EVEN lane's
+// chain (even lane: half 0, odd lane: half 1 - one 64-byte line per pair), in group II the record of the ODD lane's chain.  Each lane
+// tests "its" child for both chains (with a resident copy of the partner's ray), then the foreign result is handed over by DPP.
+// 64 chains per wave, the slab arithmetic of A, 4 loads per lane as in A - but every load instruction touches 32 lines instead of 64.
+__device__ __forceinline__ uint32_t bcastEven(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xA0, 0xf, 0xf, true); }  // quad_perm [0,0,2,2]
+__device__ __forceinline__ uint32_t bcastOdd(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xF5, 0xf, 0xf, true); }   // quad_perm [1,1,3,3]
+__device__ __forceinline__ float halfSlab(float4 q0, float4 q1, float ox, float oy, float oz, float rx, float ry, float rz)
+{
+    const float a0 = (q0.x - ox) * rx, a1 = (q0.w - ox) * rx, b0 = (q0.y - oy) * ry, b1 = (q1.x - oy) * ry, c0 = (q0.z - oz) * rz, c1 = (q1.y - oz) * rz;
+    const float tn = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fminf(c0, c1)), tf = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fmaxf(c0, c1));
+    return tf >= tn ? tn : 1e30f;
+}
+__global__ __launch_bounds__(256) void gatherD(const float4* __restrict__ tab2, int steps, float* out, uint32_t mask)
+{
+    extern __shared__ uint32_t pad[];
+    const int gid = blockIdx.x * 256 + threadIdx.x, half = gid & 1;
+    uint32_t idx = ((uint32_t)gid * 2654435761u >> 13) & mask;
+    float acc = 0;
+    const float ox = gid * 1e-6f, oy = 0.5f, oz = 0.25f, rx = 1.5f, ry = -0.7f, rz = 0.9f;
+    const float oxE = __uint_as_float(bcastEven(__float_as_uint(ox))), oxO = __uint_as_float(bcastOdd(__float_as_uint(ox)));   // resident copies of both rays
+    const float4* base = tab2 + half * 2;
+    for (int s = 0; s < steps; s++) {
+        const uint32_t idxE = bcastEven(idx), idxO = bcastOdd(idx);
+        const float4* pE = base + (size_t)idxE * 4;
+        const float4* pO = base + (size_t)idxO * 4;
+        const float4 e0 = pE[0], e1 = pE[1], o0 = pO[0], o1 = pO[1];
+        const float rE = halfSlab(e0, e1, oxE, oy, oz, rx, ry, rz);      // my child of the even chain's record
+        const float rO = halfSlab(o0, o1, oxO, oy, oz, rx, ry, rz);      // my child of the odd chain's record
+        const uint32_t enE = __float_as_uint(e1.z), enO = __float_as_uint(o1.z);
+        // hand the foreign result to its owner: the even lane sends (rO, enO), the odd lane (rE, enE)
+        const float got = swap1(half ? rE : rO);
+        const uint32_t gotE = swap1u(half ? enE : enO);
+        const float mine = half ? rO : rE;
+        const uint32_t mineE = half ? enO : enE;
+        const float w = half ? got - mine : mine - got;                  // child 1 minus child 2
+        acc += w;
+        idx = (w > 0.0f) == (half == 0) ? mineE : gotE;
+    }
+    out[gid] = acc + (float)pad[0] * 0.0f;
+}
+
 int main(int argc, char** argv)
 {
     const int nrec = 1 << (argc > 1 ? atoi(argv[1]) : 19), steps = 64;   // table = nrec * 64 B
@@ -156,6 +197,18 @@ int main(int argc, char** argv)
                 int badc = 0; for (int i = 0; i < chains && i < total; i++) if (ra[i] != rc[i]) badc++;
                 printf("C pair blocks/CU %d x%d: %.3f ms, %.2f G records/s  mismatches vs A %d\n", perCU, mult, best, (double)chains * steps / best / 1e6, badc);
             }
+        }
+        {
+            float best = 1e9f;
+            for (int rep = 0; rep < 5; rep++) {
+                CHK(hipEventRecord(e0));
+                hipLaunchKernelGGL(gatherD, dim3(blocks), dim3(256), lds, 0, tab2, steps, out, (uint32_t)(nrec - 1));
+                CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+            }
+            CHK(hipMemcpy(rc.data(), out, (size_t)total * 4, hipMemcpyDeviceToHost));
+            int badd = 0; for (int i = 0; i < total; i++) if (ra[i] != rc[i]) badd++;
+            printf("D pair-fetch blocks/CU %d: %.3f ms, %.2f G records/s  mismatches vs A %d\n", perCU, best, (double)total * steps / best / 1e6, badd);
         }
         int bad = 0;
         if (lds >= 16 * 1024) for (int i = 0; i < total; i++) if (ra[i] != rb[i]) bad++;
