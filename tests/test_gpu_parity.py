@@ -913,6 +913,30 @@ def test_bench_scene_1080p_band_vs_oracle_counters_equal():
     d.close()
 
 
+def test_8k_full_frame_vs_oracle_bit_exact():
+    """Maximum size: a full 7680x4320 frame (33.2 M pixels, 232 M shadow-queue slots, queues of 16 B x 33 M and more) against the oracle:
+    accumulator, RNG state and extend work counters.  Exercises the persistent traversal over queues sixteen times the bench frame's,
+    the ordered scan of k_shade over 64,800 tiles and every index that must not wrap at 2^31 bytes."""
+    Wd, Hd = 7680, 4320
+    s, view = scenes.sponza_class(0.2)
+    sa = s.arrays(bvh4=False)
+    cam = scenes.camera_for(view, Wd, Hd)
+    o = Oracle(sa, Wd, Hd, **DEFAULT)
+    d = Device(Wd, Hd, **DEFAULT)
+    d.upload(sa)
+    cam["focalLength"] = d.focus(Wd // 2, Hd // 2, cam)
+    ref, seeds, e, c = o.render(cam, 1)
+    d.seed_default()
+    d.render(cam, 1)
+    assert_bits(d.read_accum(), ref, "8K frame vs oracle")
+    assert np.array_equal(d.get_seeds(), seeds)
+    dc = d.counters()
+    for k in ("rays", "tlas_visits", "inst_visits", "node_visits", "prim_tests"):
+        assert dc["extend_" + k] == e[k], (k, dc["extend_" + k], e[k])
+    assert dc["connect_rays"] == c["rays"]
+    d.close()
+
+
 def test_stage_entry_points_respect_the_contexts_max_bounces():
     """Shadow queue and counter rows are sized by cfg.max_bounces: a stage call beyond it must be refused, not written past them."""
     sa, cam, o, d = _pair(scenes.cube_scene, 64, 36, dict(DEFAULT, max_bounces=2))
