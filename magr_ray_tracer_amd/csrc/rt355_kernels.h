@@ -498,19 +498,24 @@ RT_FORCEINLINE int traverse_bvh2_packed_coherent(const DevScene& sc, TRay& r, ui
             continue;
         }
         wc.node++;
-        float4 q0, q1, q2, q3;
+        float d1, d2;
+        uint32_t e1, e2;
         const uint32_t ucur = __builtin_amdgcn_readfirstlane(cur);
         if (__ballot(cur != ucur) == 0ull) {   // every lane that is on an interior node right now is on this one
+            // the slab tests are written out in this branch too, so that they read the record from the scalar registers it was loaded
+            // into (joined with the other branch first, the record would be copied into 14 vector registers per lane and step)
             const ConstF4 p = cpairs + (size_t)ucur * 4;
             const fvec4 a = p[0], b = p[1], c = p[2], d = p[3];
-            q0 = mk4(a.x, a.y, a.z, a.w); q1 = mk4(b.x, b.y, b.z, b.w); q2 = mk4(c.x, c.y, c.z, c.w); q3 = mk4(d.x, d.y, d.z, d.w);
+            d1 = slab(r, mk4(a.x, a.y, a.z, 0.0f), mk4(a.w, b.x, b.y, 0.0f));
+            d2 = slab(r, mk4(b.z, b.w, c.x, 0.0f), mk4(c.y, c.z, c.w, 0.0f));
+            e1 = __float_as_uint(d.x); e2 = __float_as_uint(d.y);
         } else {
             const float4* p = sc.pairs + (size_t)cur * 4;
-            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+            d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
+            d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
+            e1 = __float_as_uint(q3.x); e2 = __float_as_uint(q3.y);
         }
-        float d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
-        float d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
-        uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
         if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t e = e1; e1 = e2; e2 = e; }
         if (d1 >= tLight) {
             if (sp == 0) break;
