@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--detail", type=float, default=1.0, help="sponza-class tessellation (1.0 = ~262k triangles)")
     ap.add_argument("--accel", choices=["bvh2", "bvh4"], default="bvh2")
     ap.add_argument("--shard", choices=["samples", "bands", "ibands"], default="samples")
+    ap.add_argument("--band-rows", type=int, default=0, help="ibands: rows per band (0 = a quarter of a rank's contiguous share)")
     ap.add_argument("--lanes", type=int, default=3, help="independent sample streams per GPU whose frames overlap (samples plan only; 1 = one context)")
     ap.add_argument("--extend-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -131,22 +132,21 @@ def main():
     accums = [torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}") for _ in range(lanes)]
     reduced = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}")
 
-    def make_devices(m):
-        """One lane = one context; the interleaved-band plan gives a rank several row bands = several contexts."""
-        out = []
-        for p in rdist.plans(args.shard, W, H, rank, world, m, lanes):
-            d = Device(W, H, y0=p["y0"], y1=p["y1"], accel=accel, device=local, profile=0 if args.no_profile else 1,
-                       extend_variant=args.extend_variant, shade_blocks_per_cu=1 if lanes > 1 else 0,      # several streams share the GPU:
-                       persist_blocks_per_cu=4 if lanes > 1 else 0)                                            # leave each other room
-            d.upload(sa)
-            d.bind_accum(accums[m])
-            seeds = np.zeros(p["seed_count"], np.uint32)
-            _seed_stream(seeds, p["seed_first"])
-            d.set_seeds(seeds)
-            out.append(d)
-        return out
+    # one lane = one context; the interleaved-band plan gives a rank several row bands = several contexts
+    ctx_plans = [(m, p) for m in range(lanes) for p in rdist.plans(args.shard, W, H, rank, world, m, lanes, args.band_rows or None)]
+    share = len(ctx_plans) > 1      # several contexts share the GPU: smaller footprints, so that they leave each other room
 
-    group = rdist.Lanes([d for m in range(lanes) for d in make_devices(m)])
+    def make_device(m, p):
+        d = Device(W, H, y0=p["y0"], y1=p["y1"], accel=accel, device=local, profile=0 if args.no_profile else 1,
+                   extend_variant=args.extend_variant, shade_blocks_per_cu=1 if share else 0, persist_blocks_per_cu=4 if share else 0)
+        d.upload(sa)
+        d.bind_accum(accums[m])
+        seeds = np.zeros(p["seed_count"], np.uint32)
+        _seed_stream(seeds, p["seed_first"])
+        d.set_seeds(seeds)
+        return d
+
+    group = rdist.Lanes([make_device(m, p) for m, p in ctx_plans])
     dev = group.devs[0]
     each = args.shard != "samples"     # band plans: the contexts are parts of ONE frame, every one renders every step
     cam["focalLength"] = dev.focus(W // 2, H // 2, cam)
@@ -313,7 +313,7 @@ def main():
             "config": {"workload": f"sponza-class procedural atrium ({len(sa.prims)} prims, SAH {args.accel.upper()}, "
                                    f"{len(sa.bvh2)} nodes) {W}x{H}, NEE+cosine+RR+firefly, 7 bounces; step = 1 spp frame, "
                                    f"{args.steps} spp timed per GPU (BASELINE config 3 = 256 spp) as {lanes} interleaved sample stream(s)",
-                       "shard": args.shard, "lanes": lanes, "triangles": int(len(sa.prims)), "extend_variant": args.extend_variant},
+                       "shard": args.shard, "lanes": lanes, "contexts": len(ctx_plans), "triangles": int(len(sa.prims)), "extend_variant": args.extend_variant},
             "repeats": repeats, "timed_s": round(dt, 4),
             "value_single_context": round(value_single, 3) if value_single else None,
             "rank_s": {"render": [round(x[0], 4) for x in per_rank], "all_reduce": [round(x[1], 5) for x in per_rank]},

@@ -54,7 +54,7 @@ struct RtCtx {
     bool shadeRun[RT_MAX_BOUNCES + 1] = {};           // shade(b) launched since the last k_begin_frame
     bool generated = false;                           // generate launched since the last k_begin_frame
     int stackEntries = RT_BVH2_STACK, persistGrid = 0, persistGridConnect = 0;
-    PersistTune tune{ 112, 24, 6, 8 }, tuneConnect{ 128, 32, 6, 16 }, tune4{ 64, 20, 6, 8 };   // extend (BVH2), connect, extend (BVH4): measured optima (tools/tune_extend.sh, tune_connect.sh, tune_persist.sh)
+    PersistTune tune{ 112, 24, 6, 8, 0 }, tuneConnect{ 128, 32, 6, 16, 0 }, tune4{ 64, 20, 6, 8, 0 };   // extend (BVH2), connect, extend (BVH4): measured optima (tools/tune_extend.sh, tune_connect.sh, tune_persist.sh)
     float4* dPostF = nullptr; uchar4* dPostB = nullptr;   // post-processing outputs (lazy)
     int32_t* dSteps = nullptr;   // per-ray `steps` buffer, only bound while rt_debug_enable_steps is on
     int shadeTile = kTile;  // k_shade tile = workgroup size: kTile (512), or 256 for contexts that share the GPU (RtConfig.shade_blocks_per_cu > 0)
@@ -567,16 +567,21 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
             ctx->persistGrid = std::min(ctx->persistGrid, std::min(ctx->gridMax, d * prop.multiProcessorCount));
             ctx->persistGridConnect = std::min(ctx->persistGridConnect, std::min(ctx->gridMax, d * prop.multiProcessorCount));
             ctx->tune.leafK = 16;   // contexts sharing the GPU: hold triangle events back until 16 lanes wait on a leaf (+1 % with three lanes, -0.6 % alone)
+        } else {
+            // a context with the GPU to itself: chunks after the first are dealt round-robin too (no atomic, no round trip per dequeue):
+            // 716 -> 725 M samples/s; with three contexts sharing the GPU the dynamic queue is 0.9 % better (profiles/r02_fixed_chunks.txt)
+            ctx->tune.fixedChunks = ctx->tuneConnect.fixedChunks = 1;
         }
         if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner,leafK[,blocksPerCU]" (tuning aid)
             int a = 0, b = 0, c = 0, l = 0, d = 0;
             int k = sscanf(t, "%d,%d,%d,%d,%d", &a, &b, &c, &l, &d);
-            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = ctx->tuneConnect = ctx->tune4 = PersistTune{ a, b, c, l };
+            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = ctx->tuneConnect = ctx->tune4 = PersistTune{ a, b, c, l, 0 };
             if (k == 5 && d > 0) ctx->persistGrid = ctx->persistGridConnect = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount);
         }
+        if (const char* t = getenv("RT355_FIXED_CHUNKS")) { int a = 0, b = 0; if (sscanf(t, "%d,%d", &a, &b) == 2) { ctx->tune.fixedChunks = a; ctx->tuneConnect.fixedChunks = b; } }   // extend, connect (tuning aid)
         if (const char* t = getenv("RT355_TUNE_CONNECT")) { // same fields, connect launches only
             int a = 0, b = 0, c = 0, l = 0;
-            if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l };
+            if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l, 0 };
         }
     }
     ctx->sc = sc;

@@ -787,7 +787,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int
 // all its lanes idle), so the grid always drains.
 // Work distribution: the first chunk of every wave is static (chunk id = global wave id, no atomic, so the
 // launch does not start with thousands of waves hammering one counter); further chunks are dequeued.
-struct PersistTune { int chunk, refill, inner, leafK; };   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path
+struct PersistTune { int chunk, refill, inner, leafK, fixedChunks; };   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path, chunks dealt round-robin instead of dequeued
 
 // Short queue (late bounces, and bounce 0 when it is launched with one workgroup per 256 rays): every wave gets at most one 64-ray chunk
 // and nothing is left to refill from, so run the plain one-ray-per-lane loop, which has less per-step overhead than the refill machine.
@@ -853,6 +853,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
     if (n <= nWaves * 64) { trace_short_queue<OCC, COH>(sc, q, b0, qFirst, n, renderBVH, T, rootEntry, stk, waveId, lane); return; }
     int chunkNext = min(waveId * kChunk, n), chunkEnd = min(waveId * kChunk + kChunk, n);   // wave-uniform
     bool exhausted = false;                                                                  // wave-uniform
+    int round = 0;
 
     for (;;) {
         const unsigned long long idleMask = __ballot(slot < 0);
@@ -861,8 +862,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
         if (nIdle >= kRefill && !(exhausted && chunkNext >= chunkEnd)) {
             if (chunkNext >= chunkEnd) {           // dequeue a chunk for this wave
                 int c = 0;
-                if (lane == 0) c = atomicAdd(cursor, kChunk);
-                c = __shfl(c, 0, 64) + nWaves * kChunk;
+                if (tune.fixedChunks) { round++; c = round * nWaves * kChunk + waveId * kChunk; }   // chunks dealt round-robin: no atomic, no round trip (a context with the GPU to itself)
+                else {                                                                           // dequeued: balances waves that other contexts' kernels slow down
+                    if (lane == 0) c = atomicAdd(cursor, kChunk);
+                    c = __shfl(c, 0, 64) + nWaves * kChunk;
+                }
                 chunkNext = c; chunkEnd = min(c + kChunk, n);
                 if (c >= n) { exhausted = true; chunkNext = chunkEnd = 0; }
             }
