@@ -570,7 +570,7 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         } else {
             // a context with the GPU to itself: chunks after the first are dealt round-robin too (no atomic, no round trip per dequeue):
             // 716 -> 725 M samples/s; with three contexts sharing the GPU the dynamic queue is 0.9 % better (profiles/r02_fixed_chunks.txt)
-            ctx->tune.fixedChunks = ctx->tuneConnect.fixedChunks = 1;
+            ctx->tune.fixedChunks = ctx->tuneConnect.fixedChunks = ctx->tune4.fixedChunks = 1;
         }
         if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner,leafK[,blocksPerCU]" (tuning aid)
             int a = 0, b = 0, c = 0, l = 0, d = 0;
@@ -578,7 +578,7 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
             if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = ctx->tuneConnect = ctx->tune4 = PersistTune{ a, b, c, l, 0 };
             if (k == 5 && d > 0) ctx->persistGrid = ctx->persistGridConnect = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount);
         }
-        if (const char* t = getenv("RT355_FIXED_CHUNKS")) { int a = 0, b = 0; if (sscanf(t, "%d,%d", &a, &b) == 2) { ctx->tune.fixedChunks = a; ctx->tuneConnect.fixedChunks = b; } }   // extend, connect (tuning aid)
+        if (const char* t = getenv("RT355_FIXED_CHUNKS")) { int a = 0, b = 0; if (sscanf(t, "%d,%d", &a, &b) == 2) { ctx->tune.fixedChunks = ctx->tune4.fixedChunks = a; ctx->tuneConnect.fixedChunks = b; } }   // extend, connect (tuning aid)
         if (const char* t = getenv("RT355_TUNE_CONNECT")) { // same fields, connect launches only
             int a = 0, b = 0, c = 0, l = 0;
             if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l, 0 };

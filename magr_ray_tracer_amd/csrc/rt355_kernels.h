@@ -1018,6 +1018,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist4(DevScene sc, DevQueue
     }
     int chunkNext = min(waveId * kChunk, n), chunkEnd = min(waveId * kChunk + kChunk, n);
     bool exhausted = false;
+    int round = 0;
 
     for (;;) {
         const unsigned long long idleMask = __ballot(slot < 0);
@@ -1026,8 +1027,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist4(DevScene sc, DevQueue
         if (nIdle >= kRefill && !(exhausted && chunkNext >= chunkEnd)) {
             if (chunkNext >= chunkEnd) {
                 int c = 0;
-                if (lane == 0) c = atomicAdd(cursor, kChunk);
-                c = __shfl(c, 0, 64) + nWaves * kChunk;
+                if (tune.fixedChunks) { round++; c = round * nWaves * kChunk + waveId * kChunk; }   // see k_trace_persist
+                else {
+                    if (lane == 0) c = atomicAdd(cursor, kChunk);
+                    c = __shfl(c, 0, 64) + nWaves * kChunk;
+                }
                 chunkNext = c; chunkEnd = min(c + kChunk, n);
                 if (c >= n) { exhausted = true; chunkNext = chunkEnd = 0; }
             }
