@@ -1015,3 +1015,8 @@ extern "C" int rt_postproc(RtCtx* ctx, int32_t frames, float vignette, float gam
     ev_collect(ctx);
     return RT_OK;
 }
+
+#ifdef RT355_TAIL_PROBE
+// lab build only: copies the per-wave probe records of the last persistent launches out (9 x 8192 x 4 uint64, see rt355_kernels.h)
+extern "C" int rt_lab_tail_probe(void* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(rt355dev::g_tp), sizeof(rt355dev::g_tp)) == hipSuccess ? 0 : 1; }
+#endif

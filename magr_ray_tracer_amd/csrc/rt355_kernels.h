@@ -787,6 +787,13 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int
 // all its lanes idle), so the grid always drains.
 // Work distribution: the first chunk of every wave is static (chunk id = global wave id, no atomic, so the
 // launch does not start with thousands of waves hammering one counter); further chunks are dequeued.
+#ifdef RT355_TAIL_PROBE
+// lab build only (tools/lab/tail_probe.sh): when does the queue of a persistent launch run dry, and when do its waves exit?  One record per
+// launch slot (extend of bounce b: b, connect: 8) and wave, plain stores to distinct addresses (nothing shared, so the probe does not
+// disturb what it measures): wall_clock64 at start, when the wave found the queue dry (0: never), at exit.  Read by rt_lab_tail_probe.
+static constexpr int kTpWaves = 8192;
+__device__ unsigned long long g_tp[9][kTpWaves][4];
+#endif
 struct PersistTune { int chunk, refill, inner, leafK, fixedChunks; };   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path, chunks dealt round-robin instead of dequeued
 
 // Short queue (late bounces, and bounce 0 when it is launched with one workgroup per 256 rays): every wave gets at most one 64-ray chunk
@@ -850,7 +857,18 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
     int slot = -1, steps = 0;
     float tLight = 0;
     const int nWaves = gridDim.x * (kBlock / 64), waveId = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (n <= nWaves * 64) { trace_short_queue<OCC, COH>(sc, q, b0, qFirst, n, renderBVH, T, rootEntry, stk, waveId, lane); return; }
+#ifdef RT355_TAIL_PROBE
+    const unsigned long long tp0 = wall_clock64();
+    unsigned long long tpDry = 0;
+#define TAIL_PROBE_EXIT() if (lane == 0 && waveId < kTpWaves) { unsigned long long* w = g_tp[OCC ? 8 : b0][waveId]; w[0] = tp0; w[1] = tpDry; w[2] = wall_clock64(); w[3] = rays; }
+#endif
+    if (n <= nWaves * 64) {
+        trace_short_queue<OCC, COH>(sc, q, b0, qFirst, n, renderBVH, T, rootEntry, stk, waveId, lane);
+#ifdef RT355_TAIL_PROBE
+        TAIL_PROBE_EXIT()
+#endif
+        return;
+    }
     int chunkNext = min(waveId * kChunk, n), chunkEnd = min(waveId * kChunk + kChunk, n);   // wave-uniform
     bool exhausted = false;                                                                  // wave-uniform
     int round = 0;
@@ -869,6 +887,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
                 }
                 chunkNext = c; chunkEnd = min(c + kChunk, n);
                 if (c >= n) { exhausted = true; chunkNext = chunkEnd = 0; }
+#ifdef RT355_TAIL_PROBE
+                if (exhausted) tpDry = wall_clock64();
+#endif
             }
             if (chunkNext < chunkEnd) {
                 const int rank = __popcll(idleMask & ((1ull << lane) - 1ull));
@@ -948,6 +969,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
             }
         }
     }
+#ifdef RT355_TAIL_PROBE
+    TAIL_PROBE_EXIT()
+#endif
     flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
 }
 
