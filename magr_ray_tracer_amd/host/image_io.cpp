@@ -8,8 +8,9 @@
 //   * LoadImageF keeps channels 0..2; grey images are expanded to r = g = b here (the reference indexes past the pixel
 //     for 1- and 2-channel files, template.cpp:1621-1623, which is undefined behaviour, not a convention to mirror);
 //   * texels are appended to Scene::textures as float4 with w = 0 (float4(float3), template.cpp:810-814).
-// JPEG files go through jpeg_io.cpp (decoders differ by +-1..2 levels in IDCT / chroma interpolation / colour rounding: unpinned).
-// Not read: interlaced PNG.  Parity of this file with stb_image is unpinned beyond the rules above.
+// JPEG files go through jpeg_io.cpp (reconstruction after stb_image's arithmetic).  Not read: interlaced PNG.
+// Pinned: tests/test_ref_io_cpu.py compares LoadTexture with the reference's LoadImageF (its vendored stb_image compiled where it
+// lies, oracle/ref_io_runner.cpp) bit for bit on the reference's own image files and on synthetic files of every variant.
 #include <cmath>
 #include <cstdio>
 #include <cstring>

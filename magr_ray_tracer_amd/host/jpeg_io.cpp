@@ -1,11 +1,19 @@
 // jpeg_io.cpp — JPEG reader for Scene::LoadTexture (the reference's sponza textures are .JPG files, read there by the vendored
-// stb_image through LoadImageF, template/template.cpp:1613-1627).  Written from ITU-T T.81: baseline / extended sequential (SOF0,
-// SOF1) and progressive (SOF2) Huffman coding, 8-bit samples, 1 or 3 components (YCbCr per JFIF, or RGB when an Adobe APP14 marker
-// says so), any sampling factors, restart intervals.  Arithmetic choices where T.81 leaves freedom: a separable floating-point
-// inverse DCT, the triangle ("fancy") chroma interpolation that libjpeg documents for 2:1 factors (pixel replication otherwise) and
-// JFIF's YCbCr->RGB equations with rounding.  Decoders differ by +-1..2 levels in exactly these places, stb_image included, and no
-// reference test pins its output: parity of JPEG texels is UNPINNED; the unit test holds this reader to Pillow/libjpeg-turbo
-// within a small tolerance instead.  Not read: arithmetic coding, lossless and hierarchical modes, 12-bit samples, CMYK.
+// stb_image through LoadImageF, template/template.cpp:1613-1627).  The entropy decoding is written from ITU-T T.81: baseline /
+// extended sequential (SOF0, SOF1) and progressive (SOF2) Huffman coding, 8-bit samples, 1 or 3 components, any sampling factors,
+// restart intervals - coefficients are integers, every conforming decoder gets the same ones.  Where T.81 leaves freedom the
+// reference's decoder decides what a texel is, so the RECONSTRUCTION follows the arithmetic of lib/stb_image.h v2.27 operation by
+// operation (restated here, checked against that header compiled where it lies: tests/test_ref_io_cpu.py, 21 sponza textures and
+// synthetic files bit for bit):
+//   * dequantised coefficients wrap to 16 bits (stb_image.h:2231-2262, 3039-3043);
+//   * the inverse DCT is the Loeffler-Ligtenberg-Moschytz integer transform of IJG's jidctint with 12-bit constants, two extra bits
+//     after the column pass, rounding and the +128 level shift folded into the row pass (:2392-2489);
+//   * chroma is interpolated row by row as the image is produced: nearer sample 3/4 + further 1/4 with "+2 >> 2" (h2v1, v2) or
+//     (3a + b) per row then (3t0 + t1 + 8) >> 4 (h2v2), first and last sample of a row from one tap, the nearer / further ROW
+//     chosen by a per-component step counter that starts half a step in; other factors repeat samples (:3400-3602, 3871-3888);
+//   * YCbCr -> RGB in 20-bit fixed point with the green Cb term masked to its high 16 bits (:3603-3632); components named 'R','G','B',
+//     or an Adobe APP14 transform of 0 without a JFIF marker, are taken as RGB (:3825).
+// Not read: arithmetic coding, lossless and hierarchical modes, 12-bit samples, 4-component (CMYK / YCCK) files.
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -64,7 +72,8 @@ struct Jpeg {
     Huff dc[4], ac[4];
     std::vector<Comp> comps;
     int W = 0, H = 0, hmax = 1, vmax = 1, mcusX = 0, mcusY = 0, restart = 0;
-    bool progressive = false, adobeRGB = false;
+    bool progressive = false, jfif = false;
+    int adobeTransform = -1, rgbIds = 0;   // APP14 colour transform (-1: none), components whose id is 'R','G','B' in that order
     // entropy-coded segment reader
     uint32_t acc = 0; int nbits = 0; bool hitMarker = false;
     int eobrun = 0;
@@ -142,6 +151,7 @@ struct Jpeg {
         comps.resize((size_t)n);
         for (Comp& c : comps) {
             c.id = u8(); const int hv = u8(); c.h = hv >> 4; c.v = hv & 15; c.tq = u8();
+            if (n == 3 && c.id == "RGB"[&c - comps.data()]) rgbIds++;
             if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3) throw bad("bad JPEG sampling factors");
             hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v);
         }
@@ -264,64 +274,123 @@ struct Jpeg {
         }
     }
 
-    // ---- reconstruction ---------------------------------------------------------------------
+    // ---- reconstruction (the arithmetic of lib/stb_image.h, see the file header) ---------------------------------------------
+    static uint8_t clampLevel(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+    // one 8-point pass of the LLM inverse DCT, constants = round(c * 4096): even part into x0..x3, odd part into t0..t3.  The sums are
+    // kept modulo 2^32 (valid files stay far below; damaged ones wrap as the reference's int arithmetic does in practice, without
+    // undefined behaviour here).
+    typedef uint32_t U;
+    static void idct1d(U s0, U s1, U s2, U s3, U s4, U s5, U s6, U s7, U x[4], U t[4])
+    {
+        U p1 = (s2 + s6) * 2217u;
+        const U e2 = p1 + s6 * (U)-7567, e3 = p1 + s2 * 3135u;
+        const U e0 = (s0 + s4) * 4096u, e1 = (s0 - s4) * 4096u;
+        x[0] = e0 + e3; x[3] = e0 - e3; x[1] = e1 + e2; x[2] = e1 - e2;
+        U t0 = s7, t1 = s5, t2 = s3, t3 = s1;
+        U p3 = t0 + t2, p4 = t1 + t3, p2 = t1 + t2;
+        p1 = t0 + t3;
+        const U p5 = (p3 + p4) * 4816u;
+        t0 *= 1223u; t1 *= 8410u; t2 *= 12586u; t3 *= 6149u;
+        p1 = p5 + p1 * (U)-3685; p2 = p5 + p2 * (U)-10497; p3 *= (U)-8034; p4 *= (U)-1597;
+        t[3] = t3 + p1 + p4; t[2] = t2 + p2 + p3; t[1] = t1 + p2 + p4; t[0] = t0 + p1 + p3;
+    }
+    static int sar(U v, int n) { return (int)((int32_t)v >> n); }   // arithmetic shift of the two's-complement value
     void idctAll()
     {
-        float cosT[8][8];
-        for (int x = 0; x < 8; x++) for (int u = 0; u < 8; u++) cosT[x][u] = (float)((u ? 1.0 : std::sqrt(0.5)) * 0.5 * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0));
         for (Comp& c : comps) {
             c.pix.assign((size_t)c.bw * 8 * c.bh * 8, 0);
             const uint16_t* q = qt[c.tq];
             const size_t stride = (size_t)c.bw * 8;
             for (int by = 0; by < c.bh; by++) for (int bx = 0; bx < c.bw; bx++) {
                 const int16_t* z = &c.coef[((size_t)by * c.bw + bx) * 64];
-                float f[64], t[64];
-                for (int i = 0; i < 64; i++) f[i] = (float)(z[i] * (int)q[i]);
-                for (int v = 0; v < 8; v++) for (int x = 0; x < 8; x++) {       // rows: over u
-                    float s = 0; for (int u = 0; u < 8; u++) s += cosT[x][u] * f[v * 8 + u];
-                    t[v * 8 + x] = s;
+                int16_t d[64]; int val[64]; U x[4], t[4];
+                for (int i = 0; i < 64; i++) d[i] = (int16_t)(uint16_t)((U)(int)z[i] * (U)q[i]);
+                for (int i = 0; i < 8; i++) {                                   // columns
+                    if (!(d[i + 8] | d[i + 16] | d[i + 24] | d[i + 32] | d[i + 40] | d[i + 48] | d[i + 56])) {
+                        const int dc = d[i] * 4;
+                        for (int r = 0; r < 8; r++) val[r * 8 + i] = dc;
+                        continue;
+                    }
+                    idct1d((U)(int)d[i], (U)(int)d[i + 8], (U)(int)d[i + 16], (U)(int)d[i + 24], (U)(int)d[i + 32], (U)(int)d[i + 40], (U)(int)d[i + 48], (U)(int)d[i + 56], x, t);
+                    for (int k = 0; k < 4; k++) { x[k] += 512u; val[k * 8 + i] = sar(x[k] + t[3 - k], 10); val[(7 - k) * 8 + i] = sar(x[k] - t[3 - k], 10); }
                 }
-                for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) {       // columns: over v
-                    float s = 0; for (int v = 0; v < 8; v++) s += cosT[y][v] * t[v * 8 + x];
-                    const int p = (int)std::lrintf(s) + 128;
-                    c.pix[((size_t)by * 8 + y) * stride + (size_t)bx * 8 + x] = (uint8_t)(p < 0 ? 0 : (p > 255 ? 255 : p));
+                uint8_t* o = &c.pix[(size_t)by * 8 * stride + (size_t)bx * 8];
+                for (int r = 0; r < 8; r++, o += stride) {                      // rows: 1 << 17 to remove, rounded, level shift folded in
+                    const int* v = val + r * 8;
+                    idct1d((U)v[0], (U)v[1], (U)v[2], (U)v[3], (U)v[4], (U)v[5], (U)v[6], (U)v[7], x, t);
+                    for (int k = 0; k < 4; k++) { x[k] += 65536u + (128u << 17); o[k] = clampLevel(sar(x[k] + t[3 - k], 17)); o[7 - k] = clampLevel(sar(x[k] - t[3 - k], 17)); }
                 }
             }
         }
     }
-    // component plane at full frame resolution
-    std::vector<uint8_t> upsample(const Comp& c) const
+    // one output row of a component: `near` / `far` are the nearer and the further of the two sample rows around it
+    void resampleRow(uint8_t* out, const uint8_t* near, const uint8_t* far, int w, int hs, int vs) const
     {
-        const int fw = mcusX * 8 * hmax, fh = mcusY * 8 * vmax, hs = hmax / c.h, vs = vmax / c.v;
-        const int cwp = c.bw * 8, chp = c.bh * 8;
-        std::vector<uint8_t> out((size_t)fw * fh);
-        if (hmax % c.h || vmax % c.v) throw bad("fractional JPEG sampling ratios are not supported");
-        if (hs == 1 && vs == 1) return c.pix;
-        // samples that carry image data (the padding of the last MCU must not bleed into the triangle filter)
-        const int vw = std::min(cwp, (W * c.h + hmax - 1) / hmax), vh = std::min(chp, (H * c.v + vmax - 1) / vmax);
-        auto at = [&](int x, int y) { x = x < 0 ? 0 : (x >= vw ? vw - 1 : x); y = y < 0 ? 0 : (y >= vh ? vh - 1 : y); return (int)c.pix[(size_t)y * cwp + x]; };
-        if (hs == 2 && vs == 1) {                                 // h2v1: 3/4 nearer + 1/4 further sample
-            for (int y = 0; y < fh; y++) for (int x = 0; x < fw; x++) {
-                const int i = x >> 1, cy = y;
-                out[(size_t)y * fw + x] = (uint8_t)((x & 1) ? (3 * at(i, cy) + at(i + 1, cy) + 2) >> 2 : (3 * at(i, cy) + at(i - 1, cy) + 1) >> 2);
-            }
-        } else if (hs == 2 && vs == 2) {                          // h2v2: the same weights in both directions (9:3:3:1)/16
-            for (int y = 0; y < fh; y++) {
-                const int j = y >> 1, jn = (y & 1) ? j + 1 : j - 1;
-                for (int x = 0; x < fw; x++) {
-                    const int i = x >> 1, in = (x & 1) ? i + 1 : i - 1;
-                    const int cur = 3 * at(i, j) + at(i, jn), nb = 3 * at(in, j) + at(in, jn);
-                    out[(size_t)y * fw + x] = (uint8_t)((3 * cur + nb + ((x & 1) ? 7 : 8)) >> 4);
-                }
-            }
-        } else {
-            for (int y = 0; y < fh; y++) for (int x = 0; x < fw; x++) out[(size_t)y * fw + x] = (uint8_t)at(x / hs, y / vs);
+        if (hs == 1 && vs == 1) { memcpy(out, near, (size_t)w); return; }
+        if (hs == 1 && vs == 2) { for (int i = 0; i < w; i++) out[i] = (uint8_t)((3 * near[i] + far[i] + 2) >> 2); return; }
+        if (hs == 2 && vs == 1) {
+            if (w == 1) { out[0] = out[1] = near[0]; return; }
+            out[0] = near[0];
+            out[1] = (uint8_t)((near[0] * 3 + near[1] + 2) >> 2);
+            int i = 1;
+            for (; i < w - 1; i++) { const int n = 3 * near[i] + 2; out[i * 2] = (uint8_t)((n + near[i - 1]) >> 2); out[i * 2 + 1] = (uint8_t)((n + near[i + 1]) >> 2); }
+            out[i * 2] = (uint8_t)((near[w - 2] * 3 + near[w - 1] + 2) >> 2);
+            out[i * 2 + 1] = near[w - 1];
+            return;
         }
-        return out;
+        if (hs == 2 && vs == 2) {
+            if (w == 1) { out[0] = out[1] = (uint8_t)((3 * near[0] + far[0] + 2) >> 2); return; }
+            int t1 = 3 * near[0] + far[0];
+            out[0] = (uint8_t)((t1 + 2) >> 2);
+            for (int i = 1; i < w; i++) {
+                const int t0 = t1;
+                t1 = 3 * near[i] + far[i];
+                out[i * 2 - 1] = (uint8_t)((3 * t0 + t1 + 8) >> 4);
+                out[i * 2] = (uint8_t)((3 * t1 + t0 + 8) >> 4);
+            }
+            out[w * 2 - 1] = (uint8_t)((t1 + 2) >> 2);
+            return;
+        }
+        for (int i = 0; i < w; i++) for (int k = 0; k < hs; k++) out[i * hs + k] = near[i];   // any other factor: samples repeated (rows too)
+    }
+    // the whole image, row by row, as 8-bit RGB (a one-component file: r = g = b)
+    void produce(std::vector<uint8_t>& rgb) const
+    {
+        const size_t n = comps.size();
+        struct Step { int hs, vs, ystep, wLo, ypos, rows; const uint8_t* line0; const uint8_t* line1; size_t stride; std::vector<uint8_t> buf; };
+        std::vector<Step> st(n);
+        for (size_t k = 0; k < n; k++) {
+            const Comp& c = comps[k];
+            if (hmax % c.h || vmax % c.v) throw bad("fractional JPEG sampling ratios are not supported");
+            Step& r = st[k];
+            r.hs = hmax / c.h; r.vs = vmax / c.v; r.ystep = r.vs >> 1; r.wLo = (W + r.hs - 1) / r.hs; r.ypos = 0;
+            r.rows = (H * c.v + vmax - 1) / vmax;                       // sample rows that carry image data
+            r.stride = (size_t)c.bw * 8; r.line0 = r.line1 = c.pix.data();
+            r.buf.assign((size_t)W + 8, 0);
+        }
+        const bool isRgb = n == 3 && (rgbIds == 3 || (adobeTransform == 0 && !jfif));
+        rgb.resize((size_t)W * H * 3);
+        for (int j = 0; j < H; j++) {
+            for (size_t k = 0; k < n; k++) {
+                Step& r = st[k];
+                const bool bot = r.ystep >= (r.vs >> 1);
+                resampleRow(r.buf.data(), bot ? r.line1 : r.line0, bot ? r.line0 : r.line1, r.wLo, r.hs, r.vs);
+                if (++r.ystep >= r.vs) { r.ystep = 0; r.line0 = r.line1; if (++r.ypos < r.rows) r.line1 += r.stride; }
+            }
+            uint8_t* o = &rgb[(size_t)j * W * 3];
+            if (n == 1) { for (int i = 0; i < W; i++, o += 3) o[0] = o[1] = o[2] = st[0].buf[(size_t)i]; continue; }
+            const uint8_t *y = st[0].buf.data(), *pcb = st[1].buf.data(), *pcr = st[2].buf.data();
+            for (int i = 0; i < W; i++, o += 3) {
+                if (isRgb) { o[0] = y[i]; o[1] = pcb[i]; o[2] = pcr[i]; continue; }
+                const int yf = (y[i] << 20) + (1 << 19), cr = pcr[i] - 128, cb = pcb[i] - 128;
+                const int r = (yf + cr * 1470208) >> 20;
+                const int g = (int)(yf + cr * -748800 + (int)((unsigned)(cb * -360960) & 0xffff0000u)) >> 20;
+                const int b = (yf + cb * 1858048) >> 20;
+                o[0] = clampLevel(r); o[1] = clampLevel(g); o[2] = clampLevel(b);
+            }
+        }
     }
 };
-
-inline uint8_t clamp8(float v) { const int i = (int)std::lrintf(v); return (uint8_t)(i < 0 ? 0 : (i > 255 ? 255 : i)); }
 
 } // namespace
 
@@ -348,7 +417,8 @@ void DecodeJpeg(const std::vector<uint8_t>& bytes, const std::string& file, int&
         case 0xc4: j.dht(len); break;
         case 0xdb: j.dqt(len); break;
         case 0xdd: j.restart = j.u16(); break;
-        case 0xee: if (len >= 12 && !memcmp(&bytes[j.pos], "Adobe", 5)) j.adobeRGB = bytes[j.pos + 11] == 0; break;
+        case 0xe0: if (len >= 5 && !memcmp(&bytes[j.pos], "JFIF\0", 5)) j.jfif = true; break;
+        case 0xee: if (len >= 12 && !memcmp(&bytes[j.pos], "Adobe\0", 6)) j.adobeTransform = bytes[j.pos + 11]; break;
         case 0xda:
             if (!frame) throw j.bad("JPEG scan before the frame header");
             j.sos();                                                // consumes its header and the entropy-coded data
@@ -361,23 +431,7 @@ void DecodeJpeg(const std::vector<uint8_t>& bytes, const std::string& file, int&
     if (!frame) throw j.bad("JPEG without a frame");
     j.idctAll();
     w = j.W; h = j.H;
-    rgb.resize((size_t)w * h * 3);
-    const int fw = j.mcusX * 8 * j.hmax;
-    if (j.comps.size() == 1) {
-        const std::vector<uint8_t> y = j.upsample(j.comps[0]);
-        for (int r = 0; r < h; r++) for (int c = 0; c < w; c++) { const uint8_t v = y[(size_t)r * fw + c]; uint8_t* o = &rgb[((size_t)r * w + c) * 3]; o[0] = o[1] = o[2] = v; }
-        return;
-    }
-    const std::vector<uint8_t> p0 = j.upsample(j.comps[0]), p1 = j.upsample(j.comps[1]), p2 = j.upsample(j.comps[2]);
-    for (int r = 0; r < h; r++) for (int c = 0; c < w; c++) {
-        const size_t i = (size_t)r * fw + c;
-        uint8_t* o = &rgb[((size_t)r * w + c) * 3];
-        if (j.adobeRGB) { o[0] = p0[i]; o[1] = p1[i]; o[2] = p2[i]; continue; }
-        const float Y = p0[i], cb = (float)p1[i] - 128.0f, cr = (float)p2[i] - 128.0f;
-        o[0] = clamp8(Y + 1.402f * cr);
-        o[1] = clamp8(Y - 0.344136f * cb - 0.714136f * cr);
-        o[2] = clamp8(Y + 1.772f * cb);
-    }
+    j.produce(rgb);
 }
 
 } // namespace rt355

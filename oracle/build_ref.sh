@@ -50,4 +50,9 @@ fi
 if [[ $FORCE -eq 1 || ! -s "$OUT/libref_runner.so" || "$HERE/ref_runner.cpp" -nt "$OUT/libref_runner.so" ]]; then
   /opt/rocm/bin/hipcc -O2 -fPIC -shared -x c++ "$HERE/ref_runner.cpp" -o "$OUT/libref_runner.so" -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -L/opt/rocm/lib -lamdhip64
 fi
+# the reference's asset readers: its vendored header-only libraries (lib/stb_image.h, lib/stb_image_write.h, src/tiny_obj_loader.h),
+# compiled where they lie behind own glue code (oracle/ref_io_runner.cpp) - pins Scene::LoadTexture / LoadModel / SavePNG
+if [[ $FORCE -eq 1 || ! -s "$OUT/libref_io.so" || "$HERE/ref_io_runner.cpp" -nt "$OUT/libref_io.so" ]]; then
+  g++ -O2 -fPIC -shared -w -I "$REF/lib" -I "$REF/src" "$HERE/ref_io_runner.cpp" -o "$OUT/libref_io.so"
+fi
 ls "$OUT" | wc -l

@@ -101,15 +101,15 @@ def test_obj_loader_conventions(tmp_path):
     tex = np.zeros((2, 2, 4), np.float32)
     s.AddTexture("checker.png", tex)                # LoadTexture names the material after the diffuse texture
     n = s.LoadModel(tmp_path / "m.obj", "white", pos=(10, 0, 0))
-    assert n == 3                                   # quad -> 2 triangles (fan), + 1
+    assert n == 3                                   # quad -> 2 triangles (tinyobjloader: cut along the shorter diagonal, 1-3 on a tie), + 1
     s.BuildBLAS(0, 1.0)
     sa = s.arrays()
     p = sa.prims
     assert np.all(p["objType"] == W.PRIM_TRIANGLE)
-    # first fan triangle (v1,v2,v3) with the face's vertex order reversed, translated by pos
-    assert np.allclose(p["v0"][0][:3], [11, 1, 0]) and np.allclose(p["v1"][0][:3], [11, 0, 0]) and np.allclose(p["v2"][0][:3], [10, 0, 0])
+    # first triangle (corners 1, 2, 4 of the square) with the face's vertex order reversed, translated by pos
+    assert np.allclose(p["v0"][0][:3], [10, 1, 0]) and np.allclose(p["v1"][0][:3], [11, 0, 0]) and np.allclose(p["v2"][0][:3], [10, 0, 0])
     # texcoords keep file order and get v -> 1-v
-    assert np.allclose(p["uv0"][0], [0, 1]) and np.allclose(p["uv1"][0], [1, 1]) and np.allclose(p["uv2"][0], [1, 0])
+    assert np.allclose(p["uv0"][0], [0, 1]) and np.allclose(p["uv1"][0], [1, 1]) and np.allclose(p["uv2"][0], [0, 0])
     mats = sa.mats
     assert mats[p["matIdx"][0]]["texIdx"] == 0 and mats[p["matIdx"][2]]["texIdx"] == -1   # textured face / default material
     # negative index resolves to the last vertex
@@ -142,17 +142,23 @@ def test_load_model_loads_the_mtl_textures(tmp_path):
     assert sa.prims["matIdx"][0] == sa.prims["matIdx"][1] != sa.prims["matIdx"][2]
     assert sa.mats[sa.prims["matIdx"][2]]["texIdx"] == -1                      # `plain` has no map_Kd: the default material
     assert len(sa.tex) == 12 and np.array_equal(sa.tex[:, :3], _stb_float(pix).reshape(-1, 3))
-    # loading the same model again reuses the registered texture instead of growing the atlas
+    # loading the same model again loads its images again, as the reference does (LoadTexture appends; the material of that name is replaced)
     s2 = Scene()
     s2.AddMaterial("white", material(color=(.8, .8, .8)))
     s2.LoadModel(tmp_path / "m.obj", "white")
     s2.LoadModel(tmp_path / "m.obj", "white", pos=(3, 0, 0))
-    assert len(s2.texture_array()) == 12
-    # forceDefaultMat: no texture is loaded or used
+    assert len(s2.texture_array()) == 24
+    s2.BuildBLAS(0, 1.0)
+    sa2 = s2.arrays()
+    assert sa2.mats[sa2.prims["matIdx"][3]]["texIdx"] == 12 and sa2.mats[sa2.prims["matIdx"][0]]["texIdx"] == 0
+    # forceDefaultMat: the images are still loaded (scene.cpp:190-195 does not look at the flag), no face uses them
     s3 = Scene()
     s3.AddMaterial("white", material(color=(.8, .8, .8)))
     s3.LoadModel(tmp_path / "m.obj", "white", forceDefaultMat=True)
-    assert len(s3.texture_array()) == 0
+    assert len(s3.texture_array()) == 12
+    s3.BuildBLAS(0, 1.0)
+    sa3 = s3.arrays()
+    assert all(sa3.mats[m]["texIdx"] == -1 for m in sa3.prims["matIdx"])
     # a missing image is reported, not silently rendered untextured
     (tmp_path / "tex.png").unlink()
     s4 = Scene()
@@ -389,9 +395,11 @@ def _loaded_bytes(path):
 
 
 def test_load_texture_jpeg_against_libjpeg(tmp_path):
-    """Baseline / progressive, 4:4:4 / 4:2:2 / 4:2:0 / grey, optimised Huffman tables, restart markers, odd sizes: within the +-3
-    levels by which conforming decoders differ (IDCT, chroma interpolation and colour rounding are not fixed by T.81) of
-    Pillow's libjpeg-turbo.  JPEG texel parity with the reference's stb_image is unpinned (jpeg_io.cpp)."""
+    """Sanity check against an independent decoder (Pillow's libjpeg-turbo): baseline / progressive, 4:4:4 / 4:2:2 / 4:2:0 / grey,
+    optimised Huffman tables, restart markers, odd sizes - within the few levels by which conforming decoders differ (IDCT, chroma
+    interpolation and colour rounding are not fixed by T.81).  The reconstruction follows the reference's stb_image bit for bit
+    (tests/test_ref_io_cpu.py pins that); stb_image weights the LAST chroma sample pair of an odd-width row the other way round
+    (lib/stb_image.h:3442), so the last column is left out here."""
     Image = pytest.importorskip("PIL.Image")
     rng = np.random.default_rng(5)
     yy, xx = np.mgrid[0:157, 0:203]
@@ -410,8 +418,8 @@ def test_load_texture_jpeg_against_libjpeg(tmp_path):
         ref = np.asarray(Image.open(f).convert("RGB")).astype(np.int32)
         got = _loaded_bytes(f)
         assert got.shape == ref.shape, name
-        d = np.abs(got - ref)
-        assert d.max() <= 4 and d.mean() < 0.25, (name, int(d.max()), float(d.mean()))
+        d = np.abs(got - ref)[:, :-1] if got.shape[1] > 1 else np.abs(got - ref)
+        assert d.max() <= 5 and d.mean() < 0.3, (name, int(d.max()), float(d.mean()))
 
 
 def test_load_texture_png_against_pillow(tmp_path):

@@ -65,6 +65,20 @@ int main()
         { std::ofstream o("/tmp/san_case.obj"); o << b; }
         try { Scene s; s.AddMaterial("white"); s.LoadModel("/tmp/san_case.obj", "white"); parsed++; } catch (const std::exception&) { rejected++; }
     }
+    // polygons (tinyobjloader's quad rule and ear clipping), number spellings and index forms, no texture to miss
+    const std::string poly = "v 0 0 0\nv 2 0 0\nv 2 2 0\nv 1 .5 0\nv 0 2 0\nv 1e-3 -2.5E+2 .5\nv 3 3 3\nv -1 -1 2\nvt 0.5 0.25\nvt 1 1\n"
+                             "f 1 2 3 4 5\nf 1/1 2/2 3/1 4/2\nf -1 -2 -3 -4 -5 -6 -7 -8\ng a\nf 1 2 3 4 5 6 7\no b\nf 8//1 7//1 6//1 5//1 4//1 3//1\nf 1 2\n";
+    for (int it = 0; it < 3000; it++) {
+        std::string b = poly;
+        for (int k = 0; k < 1 + (int)(rng() % 5); k++) {
+            const size_t p = rng() % b.size();
+            switch (rng() % 4) { case 0: b[p] = (char)(32 + rng() % 90); break; case 1: b.erase(p, 1 + rng() % 5); break;
+                                 case 2: b.insert(p, std::to_string((int)(rng() % 40) - 20)); break; default: b[p] = "/ .-e\n"[rng() % 6]; }
+            if (b.empty()) b = "f";
+        }
+        { std::ofstream o("/tmp/san_case.obj"); o << b; }
+        try { Scene s; s.AddMaterial("white"); s.LoadModel("/tmp/san_case.obj", "white"); parsed++; } catch (const std::exception&) { rejected++; }
+    }
     printf("san_builders: %d scenes built, OBJ: %d parsed, %d rejected, no crash\n", built, parsed, rejected);
     return 0;
 }
