@@ -8,7 +8,7 @@
 //   * LoadImageF keeps channels 0..2; grey images are expanded to r = g = b here (the reference indexes past the pixel
 //     for 1- and 2-channel files, template.cpp:1621-1623, which is undefined behaviour, not a convention to mirror);
 //   * texels are appended to Scene::textures as float4 with w = 0 (float4(float3), template.cpp:810-814).
-// JPEG files go through jpeg_io.cpp (reconstruction after stb_image's arithmetic).  Not read: interlaced PNG.
+// JPEG files go through jpeg_io.cpp (reconstruction after stb_image's arithmetic).  Interlaced (Adam7) PNG files are read.
 // Pinned: tests/test_ref_io_cpu.py compares LoadTexture with the reference's LoadImageF (its vendored stb_image compiled where it
 // lies, oracle/ref_io_runner.cpp) bit for bit on the reference's own image files and on synthetic files of every variant.
 #include <cmath>
@@ -63,50 +63,69 @@ Image8 decodePng(const std::vector<uint8_t>& b, const std::string& file)
         pos += 12 + (size_t)len;
     }
     if (!seenIhdr || w <= 0 || h <= 0 || (int64_t)w * h > kMaxTexturePixels) throw bad("bad PNG header");
-    if (interlace) throw bad("interlaced PNG is not supported");
+    if (interlace > 1) throw bad("bad PNG interlace method");
     int chan;
     switch (ctype) { case 0: chan = 1; break; case 2: chan = 3; break; case 3: chan = 1; break; case 4: chan = 2; break; case 6: chan = 4; break; default: throw bad("bad PNG colour type"); }
     if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) throw bad("unsupported PNG bit depth");
     if (ctype == 3 && (depth == 16 || plte.size() < 3)) throw bad("bad PNG palette");
     const size_t bpp = std::max<size_t>(1, (size_t)chan * depth / 8);            // filter unit in bytes
-    const size_t stride = ((size_t)w * chan * depth + 7) / 8;
-    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    auto strideOf = [&](int pw) { return ((size_t)pw * chan * depth + 7) / 8; };
+    // the image is one pass, or the seven passes of Adam7 (PNG 1.2 section 8.2): sub-images of every (dx, dy)-th pixel from (x0, y0)
+    struct Pass { int x0, y0, dx, dy; };
+    static const Pass adam7[7] = { { 0, 0, 8, 8 }, { 4, 0, 8, 8 }, { 0, 4, 4, 8 }, { 2, 0, 4, 4 }, { 0, 2, 2, 4 }, { 1, 0, 2, 2 }, { 0, 1, 1, 2 } };
+    static const Pass whole = { 0, 0, 1, 1 };
+    const Pass* passes = interlace ? adam7 : &whole;
+    const int nPasses = interlace ? 7 : 1;
+    size_t total = 0;
+    for (int p = 0; p < nPasses; p++) {
+        const int pw = (w - passes[p].x0 + passes[p].dx - 1) / passes[p].dx, ph = (h - passes[p].y0 + passes[p].dy - 1) / passes[p].dy;
+        if (pw > 0 && ph > 0) total += (strideOf(pw) + 1) * (size_t)ph;
+    }
+    std::vector<uint8_t> raw(total);
     uLongf rawLen = (uLongf)raw.size();
     if (idat.empty() || uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size()) throw bad("PNG data does not inflate");
-    // undo the scanline filters in place (PNG 1.2 section 6)
-    std::vector<uint8_t> zero(stride, 0);
-    for (int y = 0; y < h; y++) {
-        uint8_t* cur = &raw[(stride + 1) * (size_t)y];
-        const uint8_t ft = cur[0];
-        uint8_t* row = cur + 1;
-        const uint8_t* up = y ? cur - stride : zero.data();     // previous row's bytes (already unfiltered), without its filter byte
-        for (size_t x = 0; x < stride; x++) {
-            const int a = x >= bpp ? row[x - bpp] : 0, bb = up[x], c = x >= bpp ? up[x - bpp] : 0;
-            int add;
-            switch (ft) {
-            case 0: add = 0; break;
-            case 1: add = a; break;
-            case 2: add = bb; break;
-            case 3: add = (a + bb) >> 1; break;
-            case 4: { const int p = a + bb - c, pa = abs(p - a), pb = abs(p - bb), pc = abs(p - c); add = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c); break; }
-            default: throw bad("bad PNG filter");
-            }
-            row[x] = (uint8_t)(row[x] + add);
-        }
-    }
     Image8 im; im.w = w; im.h = h; im.rgb.resize((size_t)w * h * 3);
     const int scale = depth == 1 ? 255 : depth == 2 ? 85 : depth == 4 ? 17 : 1;   // grey of < 8 bits is stretched to 0..255
-    for (int y = 0; y < h; y++) {
-        const uint8_t* row = &raw[(stride + 1) * (size_t)y + 1];
-        for (int x = 0; x < w; x++) {
-            uint8_t s[4] = { 0, 0, 0, 0 };
-            if (depth >= 8) { const int bytes = depth / 8; for (int k = 0; k < chan; k++) s[k] = row[((size_t)x * chan + k) * bytes]; }   // 16 bit: high byte
-            else { const int per = 8 / depth, sh = (per - 1 - x % per) * depth; s[0] = (uint8_t)((row[x / per] >> sh) & ((1 << depth) - 1)); }
-            uint8_t* o = &im.rgb[((size_t)y * w + x) * 3];
-            if (ctype == 3) { const size_t e = (size_t)s[0] * 3; if (e + 3 > plte.size()) throw bad("PNG palette index out of range"); o[0] = plte[e]; o[1] = plte[e + 1]; o[2] = plte[e + 2]; }
-            else if (chan <= 2) { const uint8_t g = (uint8_t)(depth < 8 ? s[0] * scale : s[0]); o[0] = o[1] = o[2] = g; }
-            else { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; }
+    size_t at = 0;
+    for (int p = 0; p < nPasses; p++) {
+        const Pass& ps = passes[p];
+        const int pw = (w - ps.x0 + ps.dx - 1) / ps.dx, ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        if (pw <= 0 || ph <= 0) continue;
+        const size_t stride = strideOf(pw);
+        // undo the scanline filters in place (PNG 1.2 section 6)
+        std::vector<uint8_t> zero(stride, 0);
+        for (int y = 0; y < ph; y++) {
+            uint8_t* cur = &raw[at + (stride + 1) * (size_t)y];
+            const uint8_t ft = cur[0];
+            uint8_t* row = cur + 1;
+            const uint8_t* up = y ? cur - stride : zero.data();     // previous row's bytes (already unfiltered), without its filter byte
+            for (size_t x = 0; x < stride; x++) {
+                const int a = x >= bpp ? row[x - bpp] : 0, bb = up[x], c = x >= bpp ? up[x - bpp] : 0;
+                int add;
+                switch (ft) {
+                case 0: add = 0; break;
+                case 1: add = a; break;
+                case 2: add = bb; break;
+                case 3: add = (a + bb) >> 1; break;
+                case 4: { const int pp = a + bb - c, pa = abs(pp - a), pb = abs(pp - bb), pc = abs(pp - c); add = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c); break; }
+                default: throw bad("bad PNG filter");
+                }
+                row[x] = (uint8_t)(row[x] + add);
+            }
         }
+        for (int y = 0; y < ph; y++) {
+            const uint8_t* row = &raw[at + (stride + 1) * (size_t)y + 1];
+            for (int x = 0; x < pw; x++) {
+                uint8_t sv[4] = { 0, 0, 0, 0 };
+                if (depth >= 8) { const int bytes = depth / 8; for (int k = 0; k < chan; k++) sv[k] = row[((size_t)x * chan + k) * bytes]; }   // 16 bit: high byte
+                else { const int per = 8 / depth, sh = (per - 1 - x % per) * depth; sv[0] = (uint8_t)((row[x / per] >> sh) & ((1 << depth) - 1)); }
+                uint8_t* o = &im.rgb[((size_t)(ps.y0 + y * ps.dy) * w + (size_t)(ps.x0 + x * ps.dx)) * 3];
+                if (ctype == 3) { const size_t e = (size_t)sv[0] * 3; if (e + 3 > plte.size()) throw bad("PNG palette index out of range"); o[0] = plte[e]; o[1] = plte[e + 1]; o[2] = plte[e + 2]; }
+                else if (chan <= 2) { const uint8_t g = (uint8_t)(depth < 8 ? sv[0] * scale : sv[0]); o[0] = o[1] = o[2] = g; }
+                else { o[0] = sv[0]; o[1] = sv[1]; o[2] = sv[2]; }
+            }
+        }
+        at += (stride + 1) * (size_t)ph;
     }
     return im;
 }

@@ -52,6 +52,8 @@ for depth in (1, 2, 4, 8):
     add_image(f"p{depth}.png", _png_bytes(pix, 3, depth, palette=rng.integers(0, 256, (1 << depth, 3))))
     if depth < 8:
         add_image(f"g{depth}.png", _png_bytes(pix, 0, depth))
+for ctype, chan, depth in ((2, 3, 8), (6, 4, 16), (0, 1, 2)):
+    add_image(f"adam7_c{ctype}_d{depth}.png", _png_bytes(rng.integers(0, 1 << depth, (9, 11, chan)), ctype, depth, interlace=True))
 w, h = 13, 7
 for name, bpp, top in (("t24", 24, False), ("t32", 32, True)):
     pix = rng.integers(0, 256, (h, w, bpp // 8)).astype(np.uint8)

@@ -205,51 +205,67 @@ def test_config5_scene_two_blas_from_converted_assets():
 
 
 # ------------------------------------------------------------------ texture files (Scene::LoadTexture, image_io.cpp)
-def _png_bytes(pix, ctype, depth=8, palette=None, filters=(0, 1, 2, 3, 4)):
-    """Encode `pix` (h, w, channels) as a PNG with the given colour type, cycling through the scanline filters."""
+def _png_bytes(pix, ctype, depth=8, palette=None, filters=(0, 1, 2, 3, 4), interlace=False):
+    """Encode `pix` (h, w, channels) as a PNG with the given colour type, cycling through the scanline filters; interlace=True
+    writes the seven Adam7 passes (PNG 1.2 section 8.2)."""
     import struct
     import zlib
+    pix = np.asarray(pix)
     h, w = pix.shape[:2]
     chan = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
-    if depth == 16:
-        rows = pix.astype(">u2").reshape(h, w * chan).view(np.uint8).reshape(h, -1)
-    elif depth == 8:
-        rows = pix.astype(np.uint8).reshape(h, w * chan)
-    else:   # packed samples, most significant first
-        per = 8 // depth
-        padded = np.zeros((h, (w + per - 1) // per * per), dtype=np.uint8)
-        padded[:, :w] = pix.reshape(h, w)
-        rows = np.zeros((h, padded.shape[1] // per), dtype=np.uint8)
-        for k in range(per):
-            rows |= (padded[:, k::per] << ((per - 1 - k) * depth)).astype(np.uint8)
+    pix = pix.reshape(h, w, chan)
     bpp = max(1, chan * depth // 8)
-    raw = bytearray()
-    prev = np.zeros(rows.shape[1], dtype=np.int32)
-    for y in range(h):
-        cur = rows[y].astype(np.int32)
-        a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if bpp < cur.size else np.zeros_like(cur)
-        c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]]) if bpp < cur.size else np.zeros_like(cur)
-        ft = filters[y % len(filters)]
-        if ft == 0:
-            f = cur
-        elif ft == 1:
-            f = cur - a
-        elif ft == 2:
-            f = cur - prev
-        elif ft == 3:
-            f = cur - ((a + prev) >> 1)
-        else:
-            p = a + prev - c
-            pa, pb, pc = abs(p - a), abs(p - prev), abs(p - c)
-            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
-            f = cur - pred
-        raw.append(ft)
-        raw += bytes((f & 255).astype(np.uint8))
-        prev = cur
+
+    def filtered(sub):
+        sh, sw = sub.shape[:2]
+        if depth == 16:
+            rows = sub.astype(">u2").reshape(sh, sw * chan).view(np.uint8).reshape(sh, -1)
+        elif depth == 8:
+            rows = sub.astype(np.uint8).reshape(sh, sw * chan)
+        else:   # packed samples, most significant first
+            per = 8 // depth
+            padded = np.zeros((sh, (sw + per - 1) // per * per), dtype=np.uint8)
+            padded[:, :sw] = sub.reshape(sh, sw)
+            rows = np.zeros((sh, padded.shape[1] // per), dtype=np.uint8)
+            for k in range(per):
+                rows |= (padded[:, k::per] << ((per - 1 - k) * depth)).astype(np.uint8)
+        raw = bytearray()
+        prev = np.zeros(rows.shape[1], dtype=np.int32)
+        for y in range(sh):
+            cur = rows[y].astype(np.int32)
+            a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if bpp < cur.size else np.zeros_like(cur)
+            c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]]) if bpp < cur.size else np.zeros_like(cur)
+            ft = filters[y % len(filters)]
+            if ft == 0:
+                f = cur
+            elif ft == 1:
+                f = cur - a
+            elif ft == 2:
+                f = cur - prev
+            elif ft == 3:
+                f = cur - ((a + prev) >> 1)
+            else:
+                p = a + prev - c
+                pa, pb, pc = abs(p - a), abs(p - prev), abs(p - c)
+                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+                f = cur - pred
+            raw.append(ft)
+            raw += bytes((f & 255).astype(np.uint8))
+            prev = cur
+        return raw
+
+    if interlace:
+        raw = bytearray()
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = pix[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += filtered(sub)
+    else:
+        raw = filtered(pix)
 
     def chunk(t, d):
         return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
-    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, int(interlace)))
     if palette is not None:
         out += chunk(b"PLTE", bytes(palette.astype(np.uint8).reshape(-1)))
     z = zlib.compress(bytes(raw), 6)

@@ -101,6 +101,15 @@ def test_png_variants_decode_like_stb_image(tmp_path):
         f.write_bytes(_png_bytes(pix, 3, 8, palette=rng.integers(0, 256, (256, 3))))
         check_image(f); n += 1
     assert n == 3 * (8 + 6 + 1)
+    # interlaced (Adam7) files, sizes below and above one 8 x 8 pattern
+    for w, h in ((1, 1), (2, 3), (5, 5), (8, 8), (9, 17), (33, 18), (64, 3)):
+        for ctype, chan, depth in ((2, 3, 8), (6, 4, 8), (2, 3, 16), (0, 1, 8), (0, 1, 1), (0, 1, 4), (4, 2, 8)):
+            f = tmp_path / f"i{ctype}_{depth}_{w}x{h}.png"
+            f.write_bytes(_png_bytes(rng.integers(0, 1 << depth, (h, w, chan)), ctype, depth, interlace=True))
+            check_image(f)
+        f = tmp_path / f"ip2_{w}x{h}.png"
+        f.write_bytes(_png_bytes(rng.integers(0, 4, (h, w, 1)), 3, 2, palette=rng.integers(0, 256, (4, 3)), interlace=True))
+        check_image(f)
 
 
 def jpeg_cases():
@@ -144,11 +153,53 @@ def test_tga_and_hdr_decode_like_stb_image(tmp_path):
         f = tmp_path / (name + ".tga")
         f.write_bytes(hdr + pix.tobytes())
         check_image(f)
+    # grey (type 3) and run-length coded true colour (type 10) / grey (type 11)
+    g = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    f = tmp_path / "grey.tga"
+    f.write_bytes(struct.pack("<BBBHHBHHHHBB", 0, 0, 3, 0, 0, 0, 0, 0, w, h, 8, 0) + g.tobytes())
+    check_image(f)
+    for name, typ, bpp in (("rle24", 10, 24), ("rle32", 10, 32), ("rle8", 11, 8)):
+        pix = rng.integers(0, 256, (h * w, bpp // 8)).astype(np.uint8)
+        pix[20:50] = pix[20]
+        body, i = bytearray(), 0
+        while i < len(pix):                                    # packets may cross scanlines, as the format allows
+            run = 1
+            while i + run < len(pix) and run < 128 and np.array_equal(pix[i + run], pix[i]):
+                run += 1
+            if run >= 2:
+                body += bytes([128 + run - 1]) + pix[i].tobytes(); i += run
+            else:
+                n = min(int(rng.integers(1, 6)), len(pix) - i)
+                body += bytes([n - 1]) + pix[i:i + n].tobytes(); i += n
+        f = tmp_path / (name + ".tga")
+        f.write_bytes(struct.pack("<BBBHHBHHHHBB", 0, 0, typ, 0, 0, 0, 0, 0, w, h, bpp, 0x20 | (8 if bpp == 32 else 0)) + bytes(body))
+        check_image(f)
     # Radiance RGBE, flat (non-RLE) scanlines
     rgbe = rng.integers(0, 256, (h, w, 4)).astype(np.uint8)
     rgbe[0, 0, 3] = 0
     f = tmp_path / "flat.hdr"
     f.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n" + f"-Y {h} +X {w}\n".encode() + rgbe.tobytes())
+    check_image(f)
+    # new-style run-length coded scanlines (width 8..32767): per channel, runs (128 + n, value) and literal packets (n, bytes)
+    w2 = 40
+    img = rng.integers(0, 256, (h, w2, 4)).astype(np.uint8)
+    img[:, 5:25, 1] = 77                                     # something worth a run
+    body = bytearray()
+    for y in range(h):
+        body += bytes([2, 2, w2 >> 8, w2 & 255])
+        for ch in range(4):
+            row, x = img[y, :, ch], 0
+            while x < w2:
+                run = 1
+                while x + run < w2 and run < 127 and row[x + run] == row[x]:
+                    run += 1
+                if run >= 3:
+                    body += bytes([128 + run, int(row[x])]); x += run
+                else:
+                    n = min(int(rng.integers(1, 9)), w2 - x)
+                    body += bytes([n]) + row[x:x + n].tobytes(); x += n
+    f = tmp_path / "rle.hdr"
+    f.write_bytes(b"#?RADIANCE\n# made by a test\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n" + f"-Y {h} +X {w2}\n".encode() + bytes(body))
     check_image(f)
 
 
