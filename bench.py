@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--detail", type=float, default=1.0, help="sponza-class tessellation (1.0 = ~262k triangles)")
+    ap.add_argument("--model", default=None, help="an OBJ file (e.g. a real sponza.obj) instead of the procedural atrium: scenes.model_scene")
+    ap.add_argument("--view", default=None, help="camera for --model: ox,oy,oz,fx,fy,fz[,fov] (default: the reference's CameraManager defaults)")
     ap.add_argument("--accel", choices=["bvh2", "bvh4"], default="bvh2")
     ap.add_argument("--shard", choices=["samples", "bands", "ibands"], default="samples")
     ap.add_argument("--band-rows", type=int, default=0, help="ibands: rows per band (0 = a quarter of a rank's contiguous share)")
@@ -122,7 +124,15 @@ def main():
 
     # ---- scene + BVH on the host (not timed), upload, seeds -------------------------------------------------
     t0 = time.time()
-    s, view = scenes.sponza_class(args.detail)
+    if args.model:
+        s, view = scenes.model_scene(args.model)
+        if args.view:
+            v = [float(x) for x in args.view.split(",")]
+            view.update(origin=tuple(v[0:3]), forward=tuple(v[3:6]))
+            if len(v) > 6:
+                view["fov"] = v[6]
+    else:
+        s, view = scenes.sponza_class(args.detail)
     sa = s.arrays(bvh4=bool(accel))
     build_s = time.time() - t0
     lanes = max(1, args.lanes) if args.shard == "samples" else 1
@@ -280,7 +290,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                same = tj.get("config", {}) == {"accel": args.accel, "detail": args.detail, "width": W, "height": H}
+                same = not args.model and tj.get("config", {}) == {"accel": args.accel, "detail": args.detail, "width": W, "height": H}
                 if same:
                     traffic, traffic_note = tj.get("hbm_bytes_per_launch"), tj.get("source", "")
             except Exception:
@@ -310,7 +320,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / frames_timed * 1e3, 4),
             "higher_is_better": True, "scaling": "weak" if args.shard == "samples" else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"sponza-class procedural atrium ({len(sa.prims)} prims, SAH {args.accel.upper()}, "
+            "config": {"workload": (f"model {os.path.basename(args.model)}" if args.model else "sponza-class procedural atrium") +
+                                   f" ({len(sa.prims)} prims, SAH {args.accel.upper()}, "
                                    f"{len(sa.bvh2)} nodes) {W}x{H}, NEE+cosine+RR+firefly, 7 bounces; step = 1 spp frame, "
                                    f"{args.steps} spp timed per GPU (BASELINE config 3 = 256 spp) as {lanes} interleaved sample stream(s)",
                        "shard": args.shard, "lanes": lanes, "contexts": len(ctx_plans), "triangles": int(len(sa.prims)), "extend_variant": args.extend_variant},

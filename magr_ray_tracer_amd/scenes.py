@@ -6,6 +6,7 @@ follow reference src/scene.cpp:14-43.
     cube_scene()      config 1: unit cube (12 tris) on a floor + quad light
     bunny_class()     config 2: closed displaced-sphere mesh, 2*n*n triangles (n=187 -> 69,938)
     sponza_class()    config 3/4: atrium with two arcaded storeys, columns, arches, drapes (~260k tris)
+    model_scene()     an OBJ file (a real sponza.obj when supplied) + the reference's light quad
     mixed_scene()     small scene with spheres, a mirror, glass, a texture and two lights (edge cases)
     two_blas_scene()  two BLAS under a TLAS (config 5 shape)
 """
@@ -150,6 +151,20 @@ def sponza_class(detail=1.0, alpha=1.0):
     del first_extra
     s.BuildBLAS(0, alpha)
     view = dict(origin=(-15.0, 3.2, 0.6), forward=(-0.97, -0.10, -0.05), fov=75.0, aperture=0.02)
+    return s, view
+
+
+def model_scene(path, alpha=1.0, default_material="white"):
+    """The reference's model branch (src/scene.cpp:63-69): LoadModel(path, "white") - OBJ + MTL + diffuse textures through the
+    tinyobjloader / stb_image-exact readers of the host library - plus one 4 x 4 emissive quad at the reference's coordinates, one
+    BLAS over everything, seen from CameraManager's defaults (src/camera.h:24-34).  The hook for a real assets/sponza/sponza.obj
+    (absent from the reference checkout): `python bench.py --model /path/to/sponza.obj`."""
+    s = Scene()
+    _std_materials(s)
+    s.LoadModel(path, default_material)
+    s.AddQuad((-2, 0, -7.5), (2, 0, -7.5), (2, 4, -7.5), (-2, 4, -7.5), "white-light")
+    s.BuildBLAS(0, alpha)
+    view = dict(origin=(-10.0, 10.0, 15.0), forward=(0.0, 0.0, 1.0), fov=110.0, aperture=0.1)
     return s, view
 
 

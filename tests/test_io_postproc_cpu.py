@@ -476,3 +476,17 @@ def test_load_texture_errors(tmp_path):
     f.write_bytes(_png_bytes(np.zeros((4, 4, 3), dtype=np.int64), 2)[:60])
     with pytest.raises(Exception):
         s.LoadTexture(f, "x")
+
+
+def test_model_scene_hook_renders_an_obj_file(tmp_path):
+    """scenes.model_scene (bench.py --model): an OBJ + MTL + texture through LoadModel, the reference's light quad (scene.cpp:67), one
+    BLAS - and the oracle renders it (the hook for a real sponza.obj, which the reference checkout does not contain)."""
+    pix = write_textured_obj(tmp_path)
+    s, view = scenes.model_scene(str(tmp_path / "m.obj"))
+    sa = s.arrays(bvh4=False)
+    assert len(sa.prims) == 3 + 2 and len(sa.lights) == 2 and len(sa.tex) == pix.shape[0] * pix.shape[1]
+    view.update(origin=(0.5, 0.5, 3.0), forward=(0.0, 0.0, 1.0), fov=60.0)       # the camera looks along -forward: at the model's quad in the z = 0 plane
+    cam = scenes.camera_for(view, 32, 18)
+    o = Oracle(sa, 32, 18)
+    acc, _, e, _ = o.render(cam, 2)
+    assert e["rays"] > 32 * 18 and np.isfinite(acc).all() and acc[..., :3].max() > 0
