@@ -63,6 +63,7 @@ def parse_args():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stage launches with HIP events")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (default); gloo only for rehearsals")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses GPU 0 (requires --backend gloo)")
+    ap.add_argument("--no-share-scene", action="store_true", help="every context uploads its own copy of the scene (A/B of rt_share_scene)")
     ap.add_argument("--no-single", action="store_true", help="skip the untimed single-context pass (profiler runs: only the timed workload's launches)")
     ap.add_argument("--no-repeat", action="store_true", help="time the K-step region once, however short it is")
     ap.add_argument("--dump-accum", default=None, help="rank 0 writes the reduced accumulator (npy) here after the timed region")
@@ -146,10 +147,16 @@ def main():
     ctx_plans = [(m, p) for m in range(lanes) for p in rdist.plans(args.shard, W, H, rank, world, m, lanes, args.band_rows or None)]
     share = len(ctx_plans) > 1      # several contexts share the GPU: smaller footprints, so that they leave each other room
 
+    made = []
+
     def make_device(m, p):
         d = Device(W, H, y0=p["y0"], y1=p["y1"], accel=accel, device=local, profile=0 if args.no_profile else 1,
                    extend_variant=args.extend_variant, shade_blocks_per_cu=1 if share else 0, persist_blocks_per_cu=4 if share else 0)
-        d.upload(sa)
+        if made and not args.no_share_scene:
+            d.share_scene(made[0])          # one device copy of the scene for all contexts of this rank
+        else:
+            d.upload(sa)
+        made.append(d)
         d.bind_accum(accums[m])
         seeds = np.zeros(p["seed_count"], np.uint32)
         _seed_stream(seeds, p["seed_first"])

@@ -108,6 +108,13 @@ int rt_upload_scene(RtCtx* ctx,
                     const RtTLASNode* tlas, int32_t nTlas,
                     const RtBVHInstance* blas, int32_t nBlas);
 
+/* A second context on the same device renders the scene `from` holds: it takes `from`'s device copy (uploaded arrays + derived
+ * layouts) instead of uploading its own - one copy in HBM and in the caches for the sample streams of a GPU or the row bands of a
+ * frame.  The contexts must agree in accel and extend_variant; the copy lives until the last context holding it is destroyed or
+ * uploads another scene.  (The reference has one Renderer and one set of buffers, renderer.cpp:160-208; several contexts per device
+ * are this library's way to keep a GPU full.) */
+int rt_share_scene(RtCtx* ctx, RtCtx* from);
+
 /* seedBuffer (renderer.cpp:195-196,200).  rt_set_seeds takes the band's slice
  * (one uint per band pixel); rt_seed_default fills seeds[i] with the (firstPixel+i+1)-th
  * xorshift32 output from 0x12345678 like the reference's host loop. */

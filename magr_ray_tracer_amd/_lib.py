@@ -61,7 +61,7 @@ PRIM_SPHERE, PRIM_PLANE, PRIM_TRIANGLE = 0, 1, 2
 MAX_BOUNCES = 7
 
 DEVICE_SYMBOLS = [
-    "rt_last_error", "rt_device_count", "rt_kernel_info", "rt_create", "rt_destroy", "rt_upload_scene", "rt_set_seeds", "rt_seed_default",
+    "rt_last_error", "rt_device_count", "rt_kernel_info", "rt_create", "rt_destroy", "rt_upload_scene", "rt_share_scene", "rt_set_seeds", "rt_seed_default",
     "rt_get_seeds", "rt_bind_accum", "rt_accum_device_ptr", "rt_stream", "rt_reset", "rt_render", "rt_synchronize", "rt_focus",
     "rt_read_accum", "rt_write_accum", "rt_postproc", "rt_read_counters", "rt_reset_counters", "rt_read_stage_times", "rt_reset_stage_times", "rt_set_profile",
     "rt_stage_begin_frame", "rt_stage_generate", "rt_stage_extend", "rt_stage_shade", "rt_stage_connect",
@@ -103,6 +103,7 @@ def device_lib():
         lib.rt_kernel_info.argtypes = [vp, vp]
         lib.rt_destroy.argtypes = [vp]
         lib.rt_upload_scene.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32]
+        lib.rt_share_scene.argtypes = [vp, vp]
         lib.rt_set_seeds.argtypes = [vp, vp, i64]
         lib.rt_seed_default.argtypes = [vp]
         lib.rt_get_seeds.argtypes = [vp, vp, i64]

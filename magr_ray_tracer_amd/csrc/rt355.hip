@@ -30,6 +30,14 @@ static int fail(int code, const char* fmt, ...)
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
     return fail(RT_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
+// The device copy of a scene (uploaded arrays + derived layouts).  Contexts that render the same scene - sample-stream lanes, the
+// row bands of one frame - can hold ONE copy (rt_share_scene): less HBM, and one working set in the L2s / Infinity Cache instead of one per context.
+struct SceneBag {
+    std::vector<void*> allocs;
+    int device = 0;
+    ~SceneBag() { (void)hipSetDevice(device); for (void* p : allocs) (void)hipFree(p); }
+};
+
 struct RtCtx {
     RtConfig cfg{};
     hipStream_t stream = nullptr;
@@ -38,7 +46,9 @@ struct RtCtx {
     DevVariant var{};
     int nPix = 0, firstPixel = 0, gridMax = 0;
     bool sceneLoaded = false, ownAccum = true;
-    std::vector<void*> sceneAllocs, queueAllocs;
+    std::shared_ptr<SceneBag> scene;      // shared by the contexts of rt_share_scene, freed with the last of them
+    bool singleBlas = false;              // the TLAS root is a leaf
+    std::vector<void*> queueAllocs;
     float* dFocus = nullptr;
     RtRay* dRayIO = nullptr; // debug import/export staging (lazy)
     uint64_t frames = 0, primaryRays = 0;
@@ -244,7 +254,7 @@ static void ctx_free(RtCtx* ctx)   // every owned resource; safe on a partially 
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    free_bag(ctx->sceneAllocs); free_bag(ctx->queueAllocs);
+    ctx->scene.reset(); free_bag(ctx->queueAllocs);
     if (ctx->dRayIO) (void)hipFree(ctx->dRayIO);
     if (ctx->dPostF) (void)hipFree(ctx->dPostF);
     if (ctx->dPostB) (void)hipFree(ctx->dPostB);
@@ -259,10 +269,11 @@ extern "C" int rt_destroy(RtCtx* ctx)
 }
 
 // ---- scene upload ----------------------------------------------------------------------
+static int configure_traversal(RtCtx* ctx);
 template <class T> static int upload(RtCtx* c, const T** dst, const T* src, size_t count)
 {
     T* d = nullptr;
-    int rc = dalloc(c->sceneAllocs, &d, count);
+    int rc = dalloc(c->scene->allocs, &d, count);
     if (rc != RT_OK) return rc;
     if (count) HIPCHK(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice));
     *dst = d;
@@ -368,7 +379,8 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
     }
     HIPCHK(hipSetDevice(ctx->cfg.device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    free_bag(ctx->sceneAllocs);
+    ctx->scene = std::make_shared<SceneBag>();   // (a copy shared with other contexts lives on with them)
+    ctx->scene->device = ctx->cfg.device;
     ctx->sceneLoaded = false; ctx->persist = false; ctx->persist4 = false; ctx->layout = 0;   // nothing usable until this upload has succeeded
     ctx->sc = DevScene{};
     DevScene sc{};
@@ -376,7 +388,7 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
     if (rc == RT_OK) rc = upload(ctx, &sc.mats, mats, (size_t)nMats);
     if (rc == RT_OK) { // zero-padded atlas (see texPad above)
         float4* t = nullptr;
-        rc = dalloc(ctx->sceneAllocs, &t, (size_t)nTexels + (size_t)texPad);
+        rc = dalloc(ctx->scene->allocs, &t, (size_t)nTexels + (size_t)texPad);
         if (rc == RT_OK) {
             HIPCHK(hipMemset(t, 0, sizeof(float4) * ((size_t)nTexels + (size_t)texPad)));
             if (nTexels) HIPCHK(hipMemcpy(t, textures, sizeof(float4) * (size_t)nTexels, hipMemcpyHostToDevice));
@@ -548,11 +560,22 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         if (rc == RT_OK) rc = upload(ctx, &sc.instRecs, ir.data(), ir.size());
         sc.tlasRoot = enc(0);
     }
-    if (rc != RT_OK) { free_bag(ctx->sceneAllocs); ctx->sceneLoaded = false; return rc; }
+    if (rc != RT_OK) { ctx->scene.reset(); ctx->sceneLoaded = false; return rc; }
     sc.nLights = nLights; sc.nPrims = nPrims; sc.nBlas = nBlas; sc.nTex = nTexels;
+    ctx->singleBlas = tlas[0].leftRight == 0;
+    ctx->sc = sc;
+    rc = configure_traversal(ctx);
+    if (rc != RT_OK) { ctx->scene.reset(); return rc; }
+    ctx->sceneLoaded = true;
+    return RT_OK;
+}
+
+// What a context derives from its configuration once it has a scene: which traversal kernels run and how their persistent grids are sized.
+static int configure_traversal(RtCtx* ctx)
+{
     // persistent-wavefront traversal: layout 1 and a TLAS whose root is a leaf (one BLAS)
-    ctx->persist = ctx->layout == 1 && ctx->cfg.accel == RT_ACCEL_BVH2 && tlas[0].leftRight == 0 && ctx->cfg.extend_variant != 2;
-    ctx->persist4 = ctx->layout == 1 && ctx->cfg.accel == RT_ACCEL_BVH4 && tlas[0].leftRight == 0 && ctx->cfg.extend_variant != 2;
+    ctx->persist = ctx->layout == 1 && ctx->cfg.accel == RT_ACCEL_BVH2 && ctx->singleBlas && ctx->cfg.extend_variant != 2;
+    ctx->persist4 = ctx->layout == 1 && ctx->cfg.accel == RT_ACCEL_BVH4 && ctx->singleBlas && ctx->cfg.extend_variant != 2;
     if (ctx->persist || ctx->persist4) {
         int perCU = 0; hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->cfg.device));
@@ -584,7 +607,27 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
             if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l, 0 };
         }
     }
-    ctx->sc = sc;
+    return RT_OK;
+}
+
+// A second context on the same device renders the scene `from` holds: it takes the device copy (uploaded arrays and derived layouts)
+// instead of uploading its own.  Both contexts must agree on what the derived layout depends on (accel, extend_variant).
+extern "C" int rt_share_scene(RtCtx* ctx, RtCtx* from)
+{
+    if (!ctx || !from) return fail(RT_E_INVALID, "rt_share_scene: null context");
+    if (ctx == from) return RT_OK;
+    if (!from->sceneLoaded) return fail(RT_E_INVALID, "rt_share_scene: the source context has no scene");
+    if (ctx->cfg.device != from->cfg.device) return fail(RT_E_INVALID, "rt_share_scene: contexts on different devices (%d, %d)", ctx->cfg.device, from->cfg.device);
+    if (ctx->cfg.accel != from->cfg.accel || ctx->cfg.extend_variant != from->cfg.extend_variant)
+        return fail(RT_E_INVALID, "rt_share_scene: the contexts differ in accel / extend_variant, which the derived layout depends on");
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->sceneLoaded = false;
+    ctx->scene = from->scene;
+    ctx->sc = from->sc;
+    ctx->layout = from->layout; ctx->maxDepth2 = from->maxDepth2; ctx->stackEntries = from->stackEntries; ctx->singleBlas = from->singleBlas;
+    const int rc = configure_traversal(ctx);
+    if (rc != RT_OK) { ctx->scene.reset(); return rc; }
     ctx->sceneLoaded = true;
     return RT_OK;
 }

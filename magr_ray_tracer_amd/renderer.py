@@ -61,6 +61,10 @@ class Device:
             P(sa.lights) if len(sa.lights) else None, len(sa.lights), P(nodes), len(nodes), P(sa.primIdx), len(sa.primIdx),
             P(sa.tlas), len(sa.tlas), P(sa.blas), len(sa.blas)))
 
+    def share_scene(self, other):
+        """Render the scene `other` (a Device on the same GPU, same accel) holds, from ITS device copy (rt_share_scene)."""
+        self._chk(self._lib.rt_share_scene(self._h, other._h))
+
     def kernel_info(self):
         """Which traversal kernels this context runs for the uploaded scene (rt_kernel_info)."""
         k = np.zeros((), dtype=_lib.KernelInfo)

@@ -1145,3 +1145,47 @@ def test_interleaved_bands_on_one_gpu_match_oracle_bands():
         total += acc
     assert sorted(rows) == list(range(Hd))
     assert_bits(total, exp, "interleaved bands vs oracle bands")
+
+
+def test_contexts_share_one_device_copy_of_the_scene():
+    """rt_share_scene: three contexts (two BVH2 lanes and a row band) render from the device copy the first one uploaded - each still
+    bit-exact vs the oracle on its own seeds; the copy outlives the context that uploaded it; contexts that differ in accel are refused."""
+    from magr_ray_tracer_amd import dist as rdist
+    Wd, Hd, frames = 160, 90, 3
+    s, view = scenes.sponza_class(0.2)
+    sa = s.arrays()
+    cam = scenes.camera_for(view, Wd, Hd)
+    first = Device(Wd, Hd, **DEFAULT)
+    first.upload(sa)
+    lane = Device(Wd, Hd, shade_blocks_per_cu=1, persist_blocks_per_cu=4, **DEFAULT)     # another footprint, same scene
+    lane.share_scene(first)
+    band = Device(Wd, Hd, y0=32, y1=64, **DEFAULT)
+    band.share_scene(first)
+    assert lane.kernel_info()["persist"] == 1 and lane.kernel_info()["persist_grid"] < first.kernel_info()["persist_grid"]
+    seeds = [seed_stream(rdist.plan("samples", Wd, Hd, 0, 1, m, 2)["seed_first"], Wd * Hd) for m in range(2)]
+    first.set_seeds(seeds[0]); lane.set_seeds(seeds[1]); band.seed_default()
+    for _ in range(frames):                                  # interleaved, like lanes
+        for d in (first, lane, band):
+            d.render(cam, 1)
+    o = Oracle(sa, Wd, Hd, **DEFAULT)
+    for d, sd, name in ((first, seeds[0], "uploader"), (lane, seeds[1], "sharing lane")):
+        acc, _, e, _ = o.render(cam, frames, seeds=sd.copy())     # (the oracle advances the seeds it is given)
+        assert_bits(d.read_accum(), acc, name)
+        assert d.counters()["extend_node_visits"] == e["node_visits"]
+    accb, _, _, _ = o.render(cam, frames, y0=32, y1=64)
+    assert_bits(band.read_accum()[32:64], accb[32:64], "sharing band")
+    first.close()                                            # the copy stays alive with the contexts that share it
+    before = lane.read_accum().copy()
+    lane.render(cam, 2)
+    acc, _, _, _ = o.render(cam, frames + 2, seeds=seeds[1].copy())
+    assert_bits(lane.read_accum(), acc, "after the uploader was destroyed")
+    assert not bits_equal(before, lane.read_accum())
+    q = Device(Wd, Hd, **dict(DEFAULT, accel=1))
+    with pytest.raises(RuntimeError, match="accel"):
+        q.share_scene(lane)
+    empty = Device(Wd, Hd, **DEFAULT)
+    with pytest.raises(RuntimeError, match="no scene"):
+        lane.share_scene(empty)
+    for d in (lane, band, q, empty):
+        d.close()
+
