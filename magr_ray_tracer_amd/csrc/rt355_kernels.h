@@ -93,6 +93,16 @@ struct DevVariant { int32_t shading, sampling, accel, rr, fireflies, maxBounces;
 static constexpr uint32_t kMetaBounceMask = 0xffu, kMetaInside = 0x100u, kMetaLastSpec = 0x200u;
 
 // ------------------------------------------------------------------ float4 helpers
+// Non-temporal accesses for queue data at its LAST use (k_shade's input entries and hit records, k_accumulate's shadow records) and for
+// k_generate's primary rays: what streams through once does not push node and triangle records out of the L2s.  Measured with the
+// accesses switched one group at a time (profiles/r02_nt_streams.txt): +1.0 % with three lanes, +1.4 % for one context; the same hint on
+// k_shade's STORES costs a context alone 1 % (the next extend reads them back soon), on the traversal kernels' ray loads and hit stores nothing.
+typedef float nt_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned nt_v2u __attribute__((ext_vector_type(2)));
+RT_FORCEINLINE float4 ldnt4(const float4* p) { nt_v4f t = __builtin_nontemporal_load((const nt_v4f*)p); return *(float4*)&t; }
+RT_FORCEINLINE uint2 ldnt2(const uint2* p) { nt_v2u t = __builtin_nontemporal_load((const nt_v2u*)p); return *(uint2*)&t; }
+RT_FORCEINLINE void stnt4(float4* p, float4 v) { __builtin_nontemporal_store(*(nt_v4f*)&v, (nt_v4f*)p); }
+RT_FORCEINLINE void stnt2(uint2* p, uint2 v) { __builtin_nontemporal_store(*(nt_v2u*)&v, (nt_v2u*)p); }
 RT_FORCEINLINE float4 mk4(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
 RT_FORCEINLINE float4 splat(float s) { return make_float4(s, s, s, s); }
 RT_FORCEINLINE float4 add4(float4 a, float4 b) { return mk4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -747,8 +757,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(DevQueues q, RtCamera cam, 
     float4 O, D;
     primary_ray(cam, idx % q.width, idx / q.width, q.width, q.height, aa, seed, O, D);
     q.seeds[i] = seed;
-    q.O[0][i] = O; q.D[0][i] = D; q.inten[0][i] = splat(1.0f);
-    q.meta[0][i] = make_uint2((uint32_t)idx, kMetaLastSpec); // bounces 0, inside 0, lastSpecular 1
+    stnt4(&q.O[0][i], O); stnt4(&q.D[0][i], D); stnt4(&q.inten[0][i], splat(1.0f));
+    stnt2(&q.meta[0][i], make_uint2((uint32_t)idx, kMetaLastSpec)); // bounces 0, inside 0, lastSpecular 1
 }
 
 // ------------------------------------------------------------------ k_extend (variant 0: one ray per lane)
@@ -1450,7 +1460,8 @@ __global__ __launch_bounds__(TILE, 4) void k_shade(DevScene sc, DevQueues q, Dev
     auto fetch = [&](uint32_t t, TileIn& in) {
         const int j = (int)t * TILE + threadIdx.x;
         if (t < numTiles && j < n) {
-            in.hit = q.hit[j]; in.meta = q.meta[cur][j]; in.O = q.O[cur][j]; in.D = q.D[cur][j]; in.inten = q.inten[cur][j]; in.seed = q.seeds[j];
+            in.hit = ldnt4(&q.hit[j]); in.meta = ldnt2(&q.meta[cur][j]); in.O = ldnt4(&q.O[cur][j]); in.D = ldnt4(&q.D[cur][j]); in.inten = ldnt4(&q.inten[cur][j]);   // last use
+            in.seed = q.seeds[j];
         }
     };
     // Tiles are handed out by ticket to workgroups that are RUNNING, in increasing order (kTicketClasses = 1: one counter, see there;
@@ -1621,9 +1632,9 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(DevQueues q, int bounce)
     const int first = q.nShadow[bounce], n = q.nShadow[bounce + 1] - first;
     // grid-stride: the launch is sized for a typical queue, not for the worst case of one shadow ray per pixel
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const float4 c = q.sC[first + i];
+        const float4 c = ldnt4(&q.sC[first + i]);                                 // last use
         if (c.x == 0.0f && c.y == 0.0f && c.z == 0.0f && c.w == 0.0f) continue;
-        const int pix = __float_as_int(q.sB[first + i].w);
+        const int pix = __float_as_int(ldnt4(&q.sB[first + i]).w);
         q.accum[pix] = add4(q.accum[pix], c);
     }
 }
