@@ -20,6 +20,11 @@ little (20 steps are 57 ms), so the bracketed K-step region is repeated until 0.
 import argparse
 import json
 import os
+
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, the null stream included): lanes whose streams share a
+# hardware queue are serialised (four lanes on four queues: 860 M samples/s; on eight: 1,018).  Has to be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import socket
 import subprocess
 import sys
@@ -57,7 +62,8 @@ def parse_args():
     ap.add_argument("--accel", choices=["bvh2", "bvh4"], default="bvh2")
     ap.add_argument("--shard", choices=["samples", "bands", "ibands"], default="samples")
     ap.add_argument("--band-rows", type=int, default=0, help="ibands: rows per band (0 = a quarter of a rank's contiguous share)")
-    ap.add_argument("--lanes", type=int, default=3, help="independent sample streams per GPU whose frames overlap (samples plan only; 1 = one context)")
+    ap.add_argument("--persist-blocks", type=int, default=2, help="workgroups per CU of the persistent traversal grids of contexts that share the GPU")
+    ap.add_argument("--lanes", type=int, default=4, help="independent sample streams per GPU whose frames overlap (samples plan only; 1 = one context)")
     ap.add_argument("--extend-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stage launches with HIP events")
@@ -151,7 +157,7 @@ def main():
 
     def make_device(m, p):
         d = Device(W, H, y0=p["y0"], y1=p["y1"], accel=accel, device=local, profile=0 if args.no_profile else 1,
-                   extend_variant=args.extend_variant, shade_blocks_per_cu=1 if share else 0, persist_blocks_per_cu=4 if share else 0)
+                   extend_variant=args.extend_variant, shade_blocks_per_cu=1 if share else 0, persist_blocks_per_cu=args.persist_blocks if share else 0)
         if made and not args.no_share_scene:
             d.share_scene(made[0])          # one device copy of the scene for all contexts of this rank
         else:
