@@ -61,6 +61,9 @@ int main(int argc, char** argv)
         else if (a == "--lanes" && i + 1 < argc) lanes = std::max(1, atoi(argv[++i]));
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
+    // HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, the null stream included) and serialises streams
+    // that share one: more than three lanes need more queues, and the variable has to be set before HIP initialises
+    if (lanes > 3) setenv("GPU_MAX_HW_QUEUES", "8", 0);
     try {
         // One Renderer per lane.  Lane 0 alone is the reference's main loop; further lanes are independent sample streams of the same
         // frame on the same GPU (own context and stream, the next slice of the host seed stream), ticked alternately so that the tails
@@ -91,6 +94,8 @@ int main(int argc, char** argv)
             r.camera.cam.aperture = 0.0f;
             r.camera.Fov(60);
             r.Init();
+            // the lanes render the same scene: one device copy for all of them (Init uploaded one per Renderer; this one is dropped again)
+            if (m > 0 && rt_share_scene(r.ctx, lane[0]->ctx)) throw std::runtime_error(rt_last_error());
             std::vector<uint32_t> seeds((size_t)W * H);
             if (decorrelate) {
                 // The reference seeds pixel i with the (i+1)-th output of ONE xorshift32 stream and then advances every pixel with the same
