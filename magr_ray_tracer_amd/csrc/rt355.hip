@@ -467,9 +467,13 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
                 const RtPrimitive& p = prims[primIdx[s]];
                 const RtTriangle& t = p.obj.triangle;
                 const bool plain = p.objType == RT_PRIM_TRIANGLE && t.v0.w == 0.0f && t.v1.w == 0.0f && t.v2.w == 0.0f;
-                recs[(size_t)s * 3 + 0] = make_float4(t.v0.x, t.v0.y, t.v0.z, t.v1.x);
-                recs[(size_t)s * 3 + 1] = make_float4(t.v1.y, t.v1.z, t.v2.x, t.v2.y);
-                recs[(size_t)s * 3 + 2] = make_float4(t.v2.z, f2u(primIdx[s]), f2u(plain ? 0u : 1u), 0);
+                // v0 and the edges v1 - v0, v2 - v0: the first two operations of the reference's triangle test (primitives.cl:49-50), done
+                // here once with the same IEEE subtraction (this file is built with -ffp-contract=off like the kernels)
+                const float e1x = t.v1.x - t.v0.x, e1y = t.v1.y - t.v0.y, e1z = t.v1.z - t.v0.z;
+                const float e2x = t.v2.x - t.v0.x, e2y = t.v2.y - t.v0.y, e2z = t.v2.z - t.v0.z;
+                recs[(size_t)s * 3 + 0] = make_float4(t.v0.x, t.v0.y, t.v0.z, e1x);
+                recs[(size_t)s * 3 + 1] = make_float4(e1y, e1z, e2x, e2y);
+                recs[(size_t)s * 3 + 2] = make_float4(e2z, f2u(primIdx[s]), f2u(plain ? 0u : 1u), 0);
             }
             std::vector<uint32_t> roots((size_t)nBlas);
             for (int32_t b = 0; b < nBlas; b++) roots[b] = entry(blas[b].bvhIdx);
@@ -524,9 +528,13 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
                 const RtPrimitive& p = prims[primIdx[s]];
                 const RtTriangle& t = p.obj.triangle;
                 const bool plain = p.objType == RT_PRIM_TRIANGLE && t.v0.w == 0.0f && t.v1.w == 0.0f && t.v2.w == 0.0f;
-                recs[(size_t)s * 3 + 0] = make_float4(t.v0.x, t.v0.y, t.v0.z, t.v1.x);
-                recs[(size_t)s * 3 + 1] = make_float4(t.v1.y, t.v1.z, t.v2.x, t.v2.y);
-                recs[(size_t)s * 3 + 2] = make_float4(t.v2.z, f2u(primIdx[s]), f2u(plain ? 0u : 1u), 0);
+                // v0 and the edges v1 - v0, v2 - v0: the first two operations of the reference's triangle test (primitives.cl:49-50), done
+                // here once with the same IEEE subtraction (this file is built with -ffp-contract=off like the kernels)
+                const float e1x = t.v1.x - t.v0.x, e1y = t.v1.y - t.v0.y, e1z = t.v1.z - t.v0.z;
+                const float e2x = t.v2.x - t.v0.x, e2y = t.v2.y - t.v0.y, e2z = t.v2.z - t.v0.z;
+                recs[(size_t)s * 3 + 0] = make_float4(t.v0.x, t.v0.y, t.v0.z, e1x);
+                recs[(size_t)s * 3 + 1] = make_float4(e1y, e1z, e2x, e2y);
+                recs[(size_t)s * 3 + 2] = make_float4(e2z, f2u(primIdx[s]), f2u(plain ? 0u : 1u), 0);
             }
             rc = upload(ctx, &sc.quads, quads.data(), quads.size());
             if (rc == RT_OK) rc = upload(ctx, &sc.triRecs, recs.data(), recs.size());
@@ -732,18 +740,21 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
         if (ctx->cursorUsed[bounce]) HIPCHK(hipMemsetAsync(ctx->q.cursor + bounce, 0, sizeof(int32_t), ctx->stream));
         ctx->cursorUsed[bounce] = true;
     }
+    const bool wantSteps = renderBVH != 0 || ctx->q.steps != nullptr;   // only then does the event loop keep the per-ray `steps`
     // bounce 0: primary rays are coherent and finish together, refilling buys nothing -> one ray per lane
     if (ctx->persist4)
         LAUNCH(ctx, ST_EXTEND, (k_trace_persist4<false>), bounce > 0 ? dim3(ctx->persistGrid) : grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune4);
-    else if (ctx->persist && (bounce > 0 || ctx->cfg.extend_variant == 3))
-        LAUNCH(ctx, ST_EXTEND, (k_trace_persist<false>), dim3(ctx->persistGrid), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
-    else if (ctx->persist && ctx->cfg.extend_variant != 5)
+    else if (ctx->persist && (bounce > 0 || ctx->cfg.extend_variant == 3)) {
+        if (wantSteps) LAUNCH(ctx, ST_EXTEND, (k_trace_persist<false, false, true>), dim3(ctx->persistGrid), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+        else LAUNCH(ctx, ST_EXTEND, (k_trace_persist<false>), dim3(ctx->persistGrid), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+    } else if (ctx->persist && ctx->cfg.extend_variant != 5)
         // bounce 0 through the same kernel with one workgroup per 256 rays: its "queue not longer than the grid" branch is the plain
         // one-ray-per-lane loop without the TLAS code of k_extend (60 instead of 86 VGPRs: 8 instead of 5 waves per SIMD)
     {
         // bounce 0: wave-uniform node records come through the scalar cache (traverse_bvh2_packed_coherent; RT355_COHERENT=0 switches it off for A/B runs)
         static const bool coherent = !(getenv("RT355_COHERENT") && atoi(getenv("RT355_COHERENT")) == 0);
         if (coherent && bounce == 0) LAUNCH(ctx, ST_EXTEND, (k_trace_persist<false, true>), grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+        else if (wantSteps) LAUNCH(ctx, ST_EXTEND, (k_trace_persist<false, false, true>), grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
         else LAUNCH(ctx, ST_EXTEND, (k_trace_persist<false>), grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
     }
     else if (ctx->cfg.accel == RT_ACCEL_BVH4 && ctx->layout == 1)

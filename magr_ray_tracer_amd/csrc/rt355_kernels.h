@@ -410,7 +410,7 @@ RT_FORCEINLINE int traverse_bvh2(const DevScene& sc, TRay& r, uint32_t root, uin
 //              q3 = (entry(c1), entry(c2), -, -) with c1 = nodes[i].first, c2 = c1 + 1
 //   entry(n)   = n                                   interior node id
 //              = 0x80000000 | count << 24 | first    leaf (count <= 127, first < 2^24)
-//   triRecs[s] (48 B) for every primIdx slot s: the three vertices (xyz) and the primitive id, in leaf
+//   triRecs[s] (48 B) for every primIdx slot s: v0, the edges v1 - v0 and v2 - v0 (xyz) and the primitive id, in leaf
 //              order, so a leaf's triangles are contiguous and the primIdx indirection disappears.
 // Visit order, slab arithmetic, tie rules and `steps` are those of traverse_bvh2 (bvh.cl:13-54): results
 // are bit-identical; what changes is that a step costs one dependent fetch instead of two (node header,
@@ -426,8 +426,9 @@ RT_FORCEINLINE void test_tri_packed(const DevScene& sc, uint32_t slot, TRay& r)
     const int idx = __float_as_int(c.y);
     if (__float_as_int(c.z) != 0) { test_prim(sc, idx, r); return; } // not a plain triangle: reference-layout test
     const float4 O = mk4(r.ox, r.oy, r.oz, 0.0f), D = mk4(r.dx, r.dy, r.dz, 0.0f);
-    const float4 v0 = mk4(a.x, a.y, a.z, 0.0f), v1 = mk4(a.w, b.x, b.y, 0.0f), v2 = mk4(b.z, b.w, c.x, 0.0f);
-    float4 v0v1 = sub4(v1, v0), v0v2 = sub4(v2, v0);
+    // the record holds v0 and the two edges v1 - v0, v2 - v0 (the reference's first two operations, primitives.cl:49-50, done once at
+    // upload with the same IEEE subtraction)
+    const float4 v0 = mk4(a.x, a.y, a.z, 0.0f), v0v1 = mk4(a.w, b.x, b.y, 0.0f), v0v2 = mk4(b.z, b.w, c.x, 0.0f);
     float4 pvec = cross4(D, v0v2);
     float det = dot4(v0v1, pvec);
     if (fabsf(det) < 1e-8f) return;
@@ -844,7 +845,10 @@ RT_FORCEINLINE void trace_short_queue(const DevScene& sc, const DevQueues& q, in
 }
 
 
-template <bool OCC, bool COH = false>
+// STEPS: the per-ray `steps` value of the heat map (wavefront.cl:66-67) is kept only by the instantiation that has a reader for it
+// (renderBVH or rt_debug_enable_steps); the work counters of a wave are kept in scalar registers (population counts of the masks the
+// event loop forms anyway), not per lane.
+template <bool OCC, bool COH = false, bool STEPS = false>
 __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues q, int b0, int b1, int renderBVH, PersistTune tune)
 {
     const int kChunk = tune.chunk, kRefill = tune.refill, kInner = tune.inner, kLeafK = tune.leafK;
@@ -862,6 +866,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
 
     WorkCtr wc = { 0, 0, 0, 0 };
     uint32_t rays = 0;
+    uint32_t wRays = 0, wNode = 0, wPrim = 0;    // this wave's work (wave-uniform)
     TRay r; r.t = 0; r.prim = -1; r.u = r.v = 0; r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.rx = r.ry = r.rz = 0;
     uint32_t cur = 0, sp = 0;
     int slot = -1, steps = 0;
@@ -916,8 +921,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
                     r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
                     r.t = tmax; r.prim = -1; r.u = 0.0f; r.v = 0.0f;
                     tLight = tmax; cur = rootEntry; sp = 0; steps = 0; slot = idx;
-                    rays++; wc.inst++;
                 }
+                wRays += (uint32_t)min(nIdle, chunkEnd - chunkNext);
                 chunkNext = min(chunkNext + nIdle, chunkEnd);
             }
         }
@@ -931,10 +936,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
             if ((lm | im) == 0ull) break;
             const bool doLeaf = im == 0ull || __popcll(lm) >= kLeafK;
             bool done = false, occluded = false;
+            if (!doLeaf) wNode += (uint32_t)__popcll(im);
             if (doLeaf) {
+                wPrim += (uint32_t)__popcll(lm);
                 if (atLeaf) {
                     const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
-                    wc.prim++;
                     test_tri_packed(sc, first, r);
                     if (OCC && r.t < tLight) { done = true; occluded = true; }
                     else if (count > 1) cur = kLeafBit | ((count - 1) << 24) | (first + 1);
@@ -942,7 +948,6 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
                     else cur = STK(--sp);
                 }
             } else if (act && !atLeaf) {
-                wc.node++;
                 const float4* p = sc.pairs + (size_t)cur * 4;
                 const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
@@ -962,9 +967,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
                         if (sp == 0) done = true;
                         else cur = STK(--sp);
                     } else {
-                        steps++;
+                        if (STEPS) steps++;
                         cur = e1;
-                        if (d2 < tLight) { STK(sp) = e2; sp++; steps++; }
+                        if (d2 < tLight) { STK(sp) = e2; sp++; if (STEPS) steps++; }
                     }
                 }
             }
@@ -972,8 +977,10 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
                 if (OCC) { if (occluded) q.sC[qFirst + slot] = splat(0.0f); }
                 else {
                     q.hit[slot] = mk4(r.t, __int_as_float(r.prim), r.u, r.v);
-                    if (q.steps) q.steps[slot] = steps;
-                    if (renderBVH) q.accum[q.firstPixel + slot] = splat((float)(uint32_t)steps / 255.f);
+                    if (STEPS) {
+                        if (q.steps) q.steps[slot] = steps;
+                        if (renderBVH) q.accum[q.firstPixel + slot] = splat((float)(uint32_t)steps / 255.f);
+                    }
                 }
                 slot = -1;
             }
@@ -982,6 +989,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
 #ifdef RT355_TAIL_PROBE
     TAIL_PROBE_EXIT()
 #endif
+    if (lane == 0) { rays = wRays; wc.inst = wRays; wc.node = wNode; wc.prim = wPrim; }   // the wave's totals enter the reduction once
     flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
 }
 
