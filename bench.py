@@ -299,6 +299,7 @@ def main():
         ext_bytes = extend_bytes(ctr0, accel) / ext_launches
         ext_gbs = ext_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
         ext_rec = (ctr0["extend_node_visits"] + ctr0["extend_prim_tests"]) / (st["extend_ms"] * 1e-3) if st["extend_ms"] > 0 else 0.0
+        job_rec = (ctr["extend_node_visits"] + ctr["extend_prim_tests"] + ctr["connect_node_visits"] + ctr["connect_prim_tests"]) * nshare / dt / world   # per GPU
         traffic, traffic_note = None, "no PMC measurement committed for this configuration"
         tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
         if os.path.exists(tpath):
@@ -321,6 +322,8 @@ def main():
                            "`gather` prices the kernel against what the chip sustains for its access pattern",
                 "gather": {"records_per_s": round(ext_rec, 0), "ceiling_records_per_s": GATHER_CEILING_RECORDS_PER_S,
                            "frac": round(ext_rec / GATHER_CEILING_RECORDS_PER_S, 4),
+                           # a whole GPU's share of the job: every node and triangle record its lanes fetched in the timed region (extend + connect) over the wall time
+                           "job_records_per_s": round(job_rec, 0), "job_frac": round(job_rec / GATHER_CEILING_RECORDS_PER_S, 4),
                            "note": "records = interior-node pair fetches + triangle-record fetches of all extend launches / their summed HIP-event "
                                    "time; ceiling = tools/gather_probe.hip at the table size that matches the measured L1/L2 hit rates (<= 4 MB rows, "
                                    "profiles/r02_gather_probe.log).  With lanes > 1 two contexts' launches overlap, so the per-launch rate is below "
