@@ -1189,3 +1189,41 @@ def test_contexts_share_one_device_copy_of_the_scene():
     for d in (lane, band, q, empty):
         d.close()
 
+
+def test_bench_default_path_four_lanes_one_scene_copy_vs_oracle(tmp_path):
+    """`python bench.py` as the driver runs it (four lanes on eight hardware queues, one shared device copy of the scene, HIP events on
+    lane 0), at a small frame: the bench line carries what BASELINE asks for, and the accumulator it reduced is the sum of the four
+    lanes' sample streams as the ORACLE renders them - bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from magr_ray_tracer_amd import dist as rdist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    Wd, Hd, steps = 320, 180, 10
+    dump = tmp_path / "acc.npy"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GPU_MAX_HW_QUEUES")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", str(steps), "--warmup", "0", "--no-cpu-baseline", "--no-repeat", "--no-single",
+           "--width", str(Wd), "--height", str(Hd), "--detail", "0.2", "--dump-accum", str(dump)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["lanes"] == 4 and line["config"]["contexts"] == 4 and line["steps"] == steps
+    assert line["metric"].startswith("Mrays/sec") and line["dtype"] == "f32" and line["vs_baseline"] is None and line["value"] > 0
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["achieved"] > 0 and 0 < roof["gather"]["job_frac"] < 1.5
+    got = np.load(dump)
+    s, view = scenes.sponza_class(0.2)
+    sa = s.arrays(bvh4=False)
+    cam = scenes.camera_for(view, Wd, Hd)
+    d = Device(Wd, Hd, **DEFAULT)
+    d.upload(sa)
+    cam["focalLength"] = d.focus(Wd // 2, Hd // 2, cam)          # bench focuses through its first context
+    d.close()
+    o = Oracle(sa, Wd, Hd, **DEFAULT)
+    exp = None
+    for m, frames in enumerate(rdist.lane_frames(steps, 4)):        # [3, 3, 2, 2]
+        acc, _, _, _ = o.render(cam, frames, seeds=seed_stream(rdist.plan("samples", Wd, Hd, 0, 1, m, 4)["seed_first"], Wd * Hd))
+        exp = acc if exp is None else exp + acc
+    assert_bits(got, exp, "bench accumulator vs the oracle's four sample streams")
+
