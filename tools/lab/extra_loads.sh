@@ -2,7 +2,7 @@
 # lab: librt355.so rebuilt ON THE BOX'S COPY with -DRT355_EXTRA_LOADS=n: n extra 4-byte load requests (plain cached loads by inline asm) per node event of k_trace_persist
 # (to the record the event fetches anyway: same cache line, no new data) - how much does a vector-memory REQUEST cost the traversal?
 cd $GRAFT_REPO_ROOT
-for n in 0 1 2 4 0; do
+for n in 0 1 4 0; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wno-unused-function \
     -DRT355_EXTRA_LOADS=$n magr_ray_tracer_amd/csrc/rt355.hip -o magr_ray_tracer_amd/librt355.so || exit 1
   for l in 4 1; do
