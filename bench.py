@@ -300,6 +300,7 @@ def main():
         ext_gbs = ext_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
         ext_rec = (ctr0["extend_node_visits"] + ctr0["extend_prim_tests"]) / (st["extend_ms"] * 1e-3) if st["extend_ms"] > 0 else 0.0
         job_rec = (ctr["extend_node_visits"] + ctr["extend_prim_tests"] + ctr["connect_node_visits"] + ctr["connect_prim_tests"]) * nshare / dt / world   # per GPU
+        job_gbs = (extend_bytes(ctr, accel) + extend_bytes(ctr, accel, "connect")) * nshare / dt / world / 1e9   # per GPU, extend + connect of all lanes
         traffic, traffic_note = None, "no PMC measurement committed for this configuration"
         tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
         if os.path.exists(tpath):
@@ -330,6 +331,9 @@ def main():
                                    "`single_stream` while the frame rate is higher"},
                 "single_stream": single,
                 "timed_context": "HIP events on the extend launches of lane 0 (of %d)" % len(group.devs),
+                # `achieved` / `frac` are per LAUNCH: a launch takes longer while other contexts' kernels share the GPU.  The
+                # job-level figure: algorithmic bytes of every extend and connect launch of all lanes over the wall time of the timed region
+                "job_algorithmic_gbs": round(job_gbs, 1), "job_algorithmic_frac": round(job_gbs / HBM_PEAK_GBS, 4),
                 "per_ray": {"node_visits": round(ctr["extend_node_visits"] / max(ctr["extend_rays"], 1), 2),
                             "prim_tests": round(ctr["extend_prim_tests"] / max(ctr["extend_rays"], 1), 2)}}
         out = {
