@@ -5,26 +5,30 @@ sponza 1080p 256spp").
 A step = one Renderer::RayTrace() frame (1 sample per pixel) of the sponza-class scene at 1920x1080:
 generate, 7 x (extend, shade), connect.  `value` = W*H*steps*N / t / 1e6 — the reference's own
 "Mrays/s" definition (primary samples per second, src/renderer.cpp:60-62) summed over all ranks.
-Scene, BVH and seeds are resident in HBM before the timed region.  The samples are partitioned twice (magr_ray_tracer_amd/dist.py):
-across the N ranks (one process per GPU, torch.distributed / RCCL, one all_reduce(SUM) of the accumulator inside the timed
-region) and, inside a GPU, across `--lanes` independent contexts whose frames are interleaved so that the tails of one context's
-launches are filled by the other's kernels; a rank's `steps` frames are shared out over its lanes.
+Scene, BVH and seeds are resident in HBM before the timed region.  The samples are partitioned twice: across the N ranks
+(magr_ray_tracer_amd/dist.py: one process per GPU, torch.distributed / RCCL, one all_reduce(SUM) of the accumulator inside the
+timed region) and, inside a GPU, across the `--lanes` sample streams of the LIBRARY's group handle (rt_group_*, include/rt355.h:
+what stands behind one Renderer::Tick), whose frames are queued interleaved so that the tails of one lane's launches are filled
+by the others' kernels; a rank's `steps` frames are dealt to its lanes round-robin.
 
 Launching: `python bench.py --gpus N` starts its own N ranks (fresh child processes, spawned before this process touches the
 GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks.
+`--total-steps T` renders a FIXED T-spp image split over the ranks ("scaling": "strong"; north star: 256 / 1024 spp over 8 GPUs).
 
 Timed region: exactly `--steps` frames between barrier + synchronize brackets, MAX over ranks.  A region shorter than 0.25 s says
-little (20 steps are 57 ms), so the bracketed K-step region is repeated until 0.25 s of it have been timed; `value` and
+little (20 steps are 41 ms), so the bracketed K-step region is repeated until 0.25 s of it have been timed; `value` and
 `ms_per_step` are over all repeats (`repeats` in the line).
+
+Roofline: the traversal kernels fetch ~21 MB of node and triangle records over and over, from the
+vector L1s, the L2s and the Infinity Cache - so the line prices the extend kernel at EVERY memory level it uses: bytes per launch
+from committed rocprofv3 PMC passes (profiles/r03_traffic.json, made by tools/make_traffic.py from profiles/r03_pmc_*.csv) over the
+kernel's own launch time (ONE context with the GPU to itself, kernel-attached HIP events), against that level's peak
+(/opt/skills/guides/MI355X_MICROARCH.md).  `bound` is the level with the largest fraction; every fraction is <= 1 by construction.
+SURVEY 8(d)'s algorithmic bytes stay in the line as a throughput figure (`roofline.algorithmic`), not as a fraction of HBM.
 """
 import argparse
 import json
 import os
-
-# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, the null stream included): lanes whose streams share a
-# hardware queue are serialised (four lanes on four queues: 860 M samples/s; on eight: 1,018).  Has to be set before HIP initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import socket
 import subprocess
 import sys
@@ -33,13 +37,24 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# peaks of the MI355X memory levels, /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; 6.3 measured); L2 34.5 TB/s aggregate;
+# vector L1 64 B per clock and CU = 256 CUs x 64 B x 2.4 GHz (the table's max clock: the chip clocks lower under load, so the fraction
+# is a lower estimate)
+PEAK_GBS = {"hbm": 8000.0, "l2": 34500.0, "vl1d": 256 * 64 * 2.4}
 MIN_TIMED_S = 0.25      # repeat the K-step region until this much has been timed
-# tools/gather_probe.hip on the MI355X (profiles/r02_gather_probe.log): dependent random 64-byte record fetches + two slab tests,
-# no divergence.  By table size: <= 4 MB 200 G records/s (L1/L2 resident), 8 MB 168, 32 MB 118 (Infinity Cache).  The traversal's
-# 21 MB of records are fetched with 86 % vector-L1 and 82 % L2 hits (profiles/r01_pmc_final_summary.csv), i.e. its EFFECTIVE
-# working set is the small-table regime: the honest ceiling for the access pattern is the 200 G/s row.
-GATHER_CEILING_RECORDS_PER_S = 200e9
+
+# The BASELINE.json configurations that fit one GPU (config 1 is the CPU plumbing case).  `python bench.py` = config 3, the one the
+# metric is quoted on; the others are parity-test cases that can be timed / profiled with --config (tools/r3_pmc.sh).
+CONFIGS = {
+    2: dict(label="bunny-class closed mesh, Kajiya (SHADING_SIMPLE)", scene=lambda a: __import__("magr_ray_tracer_amd.scenes", fromlist=["x"]).bunny_class(187),
+            W=1280, H=720, spp=64, accel="bvh2", shading=0),
+    3: dict(label="sponza-class procedural atrium", scene=lambda a: __import__("magr_ray_tracer_amd.scenes", fromlist=["x"]).sponza_class(a.detail),
+            W=1920, H=1080, spp=256, accel="bvh2", shading=1),
+    4: dict(label="sponza-class procedural atrium through the QBVH", scene=lambda a: __import__("magr_ray_tracer_amd.scenes", fromlist=["x"]).sponza_class(a.detail),
+            W=1920, H=1080, spp=1024, accel="bvh4", shading=1),
+    5: dict(label="robo-orb + terrarium_bot, two BLAS under a TLAS, SBVH alpha 0", scene=lambda a: __import__("magr_ray_tracer_amd.scenes", fromlist=["x"]).config5_scene(0.0),
+            W=3840, H=2160, spp=4096, accel="bvh2", shading=1),
+}
 
 
 def extend_bytes(c, accel, prefix="extend"):
@@ -52,24 +67,25 @@ def extend_bytes(c, accel, prefix="extend"):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256, help="frames (1 spp each) in the timed region; 256 = BASELINE config 3")
+    ap.add_argument("--steps", type=int, default=256, help="frames (1 spp each) per GPU in the timed region; 256 = BASELINE config 3")
+    ap.add_argument("--total-steps", type=int, default=0, help="render a fixed image of this many spp split over the ranks (strong scaling) instead of --steps per GPU")
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json configuration (3 = the one the metric is quoted on)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--detail", type=float, default=1.0, help="sponza-class tessellation (1.0 = ~262k triangles)")
     ap.add_argument("--model", default=None, help="an OBJ file (e.g. a real sponza.obj) instead of the procedural atrium: scenes.model_scene")
     ap.add_argument("--view", default=None, help="camera for --model: ox,oy,oz,fx,fy,fz[,fov] (default: the reference's CameraManager defaults)")
-    ap.add_argument("--accel", choices=["bvh2", "bvh4"], default="bvh2")
+    ap.add_argument("--accel", choices=["bvh2", "bvh4"], default=None)
     ap.add_argument("--shard", choices=["samples", "bands", "ibands"], default="samples")
     ap.add_argument("--band-rows", type=int, default=0, help="ibands: rows per band (0 = a quarter of a rank's contiguous share)")
-    ap.add_argument("--persist-blocks", type=int, default=2, help="workgroups per CU of the persistent traversal grids of contexts that share the GPU")
-    ap.add_argument("--lanes", type=int, default=4, help="independent sample streams per GPU whose frames overlap (samples plan only; 1 = one context)")
+    ap.add_argument("--persist-blocks", type=int, default=0, help="workgroups per CU of the persistent traversal grids of lanes that share the GPU (0 = the library's choice, 2)")
+    ap.add_argument("--lanes", type=int, default=0, help="sample streams per GPU (and per row band) whose frames overlap; 0 = 4 (ibands: 1), 1 = the reference's single in-order queue")
     ap.add_argument("--extend-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stage launches with HIP events")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (default); gloo only for rehearsals")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses GPU 0 (requires --backend gloo)")
-    ap.add_argument("--no-share-scene", action="store_true", help="every context uploads its own copy of the scene (A/B of rt_share_scene)")
     ap.add_argument("--no-single", action="store_true", help="skip the untimed single-context pass (profiler runs: only the timed workload's launches)")
     ap.add_argument("--no-repeat", action="store_true", help="time the K-step region once, however short it is")
     ap.add_argument("--dump-accum", default=None, help="rank 0 writes the reduced accumulator (npy) here after the timed region")
@@ -108,6 +124,32 @@ def spawn_ranks(n):
     return rc if rc >= 0 else 1
 
 
+def load_traffic(match):
+    """PMC-derived bytes per launch / per step for this configuration, if a committed measurement matches it exactly."""
+    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    try:
+        tj = json.load(open(path))
+    except Exception:
+        return None
+    for e in tj.get("entries", []):
+        if all(e.get("config", {}).get(k) == v for k, v in match.items()):
+            return e
+    return None
+
+
+def level_table(bytes_by_level, seconds):
+    """{level: {bytes, gbs, peak, frac}} and the bound (the level with the largest fraction) for `bytes` moved in `seconds`."""
+    lv = {}
+    for k in ("hbm", "l2", "vl1d"):
+        b = bytes_by_level.get(k)
+        if b is None or seconds <= 0:
+            continue
+        gbs = b / seconds / 1e9
+        lv[k] = {"bytes": int(b), "gbs": round(gbs, 1), "peak": PEAK_GBS[k], "frac": round(gbs / PEAK_GBS[k], 4)}
+    bound = max(lv, key=lambda k: lv[k]["frac"]) if lv else None
+    return lv, bound
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -116,9 +158,13 @@ def main():
         raise SystemExit("--same-device puts every rank on GPU 0, which RCCL refuses: use --backend gloo")
 
     import numpy as np
+    # librt355.so first: when it is loaded it asks HIP for eight hardware queues (lanes whose streams share a queue are serialised),
+    # which only works before HIP initialises - i.e. before the first torch.cuda call
+    from magr_ray_tracer_amd import _lib
+    _lib.device_lib()
     import torch
     from magr_ray_tracer_amd import dist as rdist, scenes
-    from magr_ray_tracer_amd.renderer import Device
+    from magr_ray_tracer_amd.renderer import Device, Group
 
     rank, world, local = rdist.init_process_group(args.backend if args.gpus > 1 else None, set_device=not args.same_device)
     if args.same_device:
@@ -126,8 +172,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
-    W, H = args.width, args.height
-    accel = 1 if args.accel == "bvh4" else 0
+    conf = CONFIGS[args.config]
+    W, H = args.width or conf["W"], args.height or conf["H"]
+    accel_name = args.accel or conf["accel"]
+    accel = 1 if accel_name == "bvh4" else 0
+    shading = conf["shading"]
 
     # ---- scene + BVH on the host (not timed), upload, seeds -------------------------------------------------
     t0 = time.time()
@@ -139,42 +188,37 @@ def main():
             if len(v) > 6:
                 view["fov"] = v[6]
     else:
-        s, view = scenes.sponza_class(args.detail)
+        s, view = conf["scene"](args)
     sa = s.arrays(bvh4=bool(accel))
     build_s = time.time() - t0
-    lanes = max(1, args.lanes) if args.shard == "samples" else 1
-    # timed region: HIP events around the extend launches only (the roofline's kernel); the per-stage table comes from a short
-    # fully-bracketed pass afterwards, outside the timed region
+    lanes = args.lanes if args.lanes > 0 else (1 if args.shard == "ibands" else 4)
     cam = scenes.camera_for(view, W, H)
-    accums = [torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}") for _ in range(lanes)]
     reduced = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}")
 
-    # one lane = one context; the interleaved-band plan gives a rank several row bands = several contexts
-    ctx_plans = [(m, p) for m in range(lanes) for p in rdist.plans(args.shard, W, H, rank, world, m, lanes, args.band_rows or None)]
-    share = len(ctx_plans) > 1      # several contexts share the GPU: smaller footprints, so that they leave each other room
-
+    # one group (= `lanes` sample streams behind one handle) per row band this rank owns; HIP events bracket the extend launches of the
+    # first group's first lane only (hundreds of launches of the roofline's kernel are timed either way)
     made = []
-
-    def make_device(m, p):
-        # HIP events bracket the extend launches of the FIRST context only: hundreds of launches of the roofline's kernel are timed either
-        # way, and the other lanes run without the event packets (with four lanes they cost 1.3 % of the frame rate)
-        d = Device(W, H, y0=p["y0"], y1=p["y1"], accel=accel, device=local, profile=0 if args.no_profile or made else 1,
-                   extend_variant=args.extend_variant, shade_blocks_per_cu=1 if share else 0, persist_blocks_per_cu=args.persist_blocks if share else 0)
-        if made and not args.no_share_scene:
-            d.share_scene(made[0])          # one device copy of the scene for all contexts of this rank
+    for p in rdist.plans(args.shard, W, H, rank, world, 0, lanes, args.band_rows or None):
+        g = Group(W, H, lanes=lanes, y0=p["y0"], y1=p["y1"], accel=accel, shading=shading, device=local,
+                  profile=0 if args.no_profile or made else 1, extend_variant=args.extend_variant, persist_blocks_per_cu=args.persist_blocks)
+        if made:
+            g.share_scene(made[0])          # one device copy of the scene for all contexts of this rank
         else:
-            d.upload(sa)
-        made.append(d)
-        d.bind_accum(accums[m])
-        seeds = np.zeros(p["seed_count"], np.uint32)
-        _seed_stream(seeds, p["seed_first"])
-        d.set_seeds(seeds)
-        return d
-
-    group = rdist.Lanes([make_device(m, p) for m, p in ctx_plans])
-    dev = group.devs[0]
-    each = args.shard != "samples"     # band plans: the contexts are parts of ONE frame, every one renders every step
+            g.upload(sa)
+        g.seed(rank * lanes if args.shard == "samples" else 0)
+        made.append(g)
+    groups = rdist.Groups(made)
+    dev = groups.devs[0]
     cam["focalLength"] = dev.focus(W // 2, H // 2, cam)
+    strong = args.total_steps > 0 or args.shard != "samples"
+    # frames this rank renders in one pass of the timed region: weak scaling (default) - `steps` per GPU; a fixed `total_steps`-spp
+    # image - its share of the samples (sample plan) or all of them for its rows (band plans)
+    if args.total_steps > 0:
+        my_steps = rdist.rank_frames(args.total_steps, rank, world) if args.shard == "samples" else args.total_steps
+        job_frames = args.total_steps
+    else:
+        my_steps = args.steps
+        job_frames = args.steps * (world if args.shard == "samples" else 1)
 
     def barrier():
         torch.cuda.synchronize()
@@ -183,10 +227,9 @@ def main():
             torch.cuda.synchronize()
 
     def reduce_all():
-        reduced.copy_(accums[0])
-        for a in accums[1:]:      # the rank's accumulator = sum of its lanes in lane order ...
-            reduced.add_(a)
-        rdist.reduce_accumulator(reduced)   # ... then the one exchange step across ranks
+        groups.sum_into(reduced)              # the rank's accumulator = its lanes added up in lane order, on the device ...
+        groups.synchronize()
+        rdist.reduce_accumulator(reduced)     # ... then the one exchange step across ranks
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
@@ -198,25 +241,24 @@ def main():
 
     # ---- warmup ------------------------------------------------------------------------------------------
     if args.warmup > 0:
-        group.render(cam, args.warmup * (1 if each else len(group)), each=each)
-        group.synchronize()
+        groups.render(cam, max(args.warmup, 1) * (lanes if args.shard == "samples" else 1))
+        groups.synchronize()
         reduce_all()
-    for d in group.devs:
-        d.reset()
-        d.synchronize()
+    groups.reset()
+    groups.synchronize()
+    for d in groups.devs:
         d.reset_counters()
         d.reset_stage_times()
-    for a in accums:
-        a.zero_()
     barrier()
 
-    # ---- timed region: exactly `steps` frames (shared out over the lanes) + the accumulator reduction, repeated ---------------
+    # ---- timed region: this rank's frames (dealt to its lanes) + the accumulator reduction, repeated -----------------------------
     dts, render_s, reduce_s = [], 0.0, 0.0
     while True:
         barrier()
         t0 = time.perf_counter()
-        group.render(cam, args.steps, each=each)
-        group.synchronize()
+        if my_steps > 0:
+            groups.render(cam, my_steps)
+        groups.synchronize()
         t1 = time.perf_counter()
         reduce_all()
         t2 = time.perf_counter()
@@ -227,7 +269,8 @@ def main():
         if args.no_repeat or sum(dts) >= MIN_TIMED_S or len(dts) >= 256:
             break
     dt, repeats = sum(dts), len(dts)
-    frames_timed = args.steps * repeats
+    frames_job = job_frames * repeats            # 1-spp frames of the whole job in the timed region
+    frames_mine = my_steps * repeats
     checksum = float(reduced[..., :3].sum().item())
     if args.dump_accum and rank == 0:
         np.save(args.dump_accum, reduced.cpu().numpy())
@@ -239,128 +282,122 @@ def main():
         per_rank = [[float(x[0]), float(x[1])] for x in allr]
 
     ctr = {}
-    for d in group.devs:          # work totals over the lanes
+    for d in groups.devs:          # work totals over this rank's contexts
         for k, v in d.counters().items():
             ctr[k] = ctr.get(k, 0) + v
-    st, ctr0 = group.devs[0].stage_times(), group.devs[0].counters()   # the context whose extend launches carry HIP events, and ITS work
+    st_lane0 = dev.stage_times()   # lane 0's extend launches while the other lanes share the GPU (diagnostic only, never a roofline time)
+    concurrency = made[0].concurrency()
 
-    # ---- untimed: ONE context with the GPU to itself (the reference's own shape: one Renderer) -----------------------------------
-    single, stage_tab, con = {}, {}, {}
+    # ---- untimed: ONE context with the GPU to itself (the reference's own shape: one Renderer, one in-order queue) ---------------
+    single, stage_tab, con, dctr, st2 = {}, {}, {}, None, None
     value_single = None
     if args.shard == "samples" and not args.no_single:
         barrier()
-        solo = dev
-        if lanes > 1:     # the lanes' contexts are configured for sharing the GPU; the single-Renderer figure gets a context of its own
-            solo = Device(W, H, accel=accel, device=local, profile=0 if args.no_profile else 1, extend_variant=args.extend_variant)
-            solo.upload(sa)
-            solo.bind_accum(torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}"))
-            seeds = np.zeros(W * H, np.uint32)
-            _seed_stream(seeds, rdist.plan("samples", W, H, rank, world)["seed_first"])
-            solo.set_seeds(seeds)
-            solo.render(cam, 2)
-            solo.synchronize()
+        solo = Device(W, H, accel=accel, shading=shading, device=local, profile=0 if args.no_profile else 1, extend_variant=args.extend_variant)
+        solo.share_scene(dev)
+        solo.bind_accum(torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}"))
+        seeds = np.zeros(W * H, np.uint32)
+        _seed_stream(seeds, rdist.plan("samples", W, H, rank, world)["seed_first"])
+        solo.set_seeds(seeds)
+        solo.render(cam, 2)
+        solo.synchronize()
         n1 = max(16, min(args.steps, 64))
         t0 = time.perf_counter()
         solo.render(cam, n1)
         solo.synchronize()
         value_single = W * H * n1 / max_over_ranks(time.perf_counter() - t0) / 1e6 * world
-        dev = solo
         if not args.no_profile and rank == 0:   # 16 more frames of that context with every stage bracketed (kernels undisturbed)
-            dev.set_profile(2)
-            dev.reset_stage_times()
-            c0 = dev.counters()
-            dev.render(cam, 16)
-            dev.synchronize()
-            st2, c1 = dev.stage_times(), dev.counters()
+            solo.set_profile(2)
+            solo.reset_stage_times()
+            c0 = solo.counters()
+            solo.render(cam, 16)
+            solo.synchronize()
+            st2, c1 = solo.stage_times(), solo.counters()
             stage_tab = {k[:-3]: round(st2[k] / 16, 4) for k in st2 if k.endswith("_ms") and k != "compact_ms"}
             dctr = {k: c1[k] - c0[k] for k in c1}
-            e_ms = st2["extend_ms"] / max(st2["extend_launches"], 1)
-            e_gbs = extend_bytes(dctr, accel) / max(st2["extend_launches"], 1) / (e_ms * 1e-3) / 1e9 if e_ms > 0 else 0.0
-            e_rec = (dctr["extend_node_visits"] + dctr["extend_prim_tests"]) / (st2["extend_ms"] * 1e-3) if st2["extend_ms"] > 0 else 0.0
-            single = {"achieved": round(e_gbs, 2), "frac": round(e_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(e_ms, 5),
-                      "gather_records_per_s": round(e_rec, 0), "gather_frac": round(e_rec / GATHER_CEILING_RECORDS_PER_S, 4),
-                      "note": "the same kernel with the GPU to itself (one context, 16 untimed frames after the timed region)"}
-            c_ms = st2["connect_ms"] / max(st2["connect_launches"], 1)
-            c_rec = (dctr["connect_node_visits"] + dctr["connect_prim_tests"]) / (st2["connect_ms"] * 1e-3) if st2["connect_ms"] > 0 else 0.0
-            c_gbs = extend_bytes(dctr, accel, "connect") / max(st2["connect_launches"], 1) / (c_ms * 1e-3) / 1e9 if c_ms > 0 else 0.0
-            con = {"achieved": round(c_gbs, 2), "frac": round(c_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(c_ms, 5),
-                   "gather_records_per_s": round(c_rec, 0), "gather_frac": round(c_rec / GATHER_CEILING_RECORDS_PER_S, 4),
-                   "rays_per_launch": dctr["connect_rays"] // max(st2["connect_launches"], 1),
-                   "note": "connect is an any-hit traversal with its own visit order; its counters are its own work, not the reference's"}
+        kernel_name = solo.extend_kernel_name()
+        solo.close()
         barrier()
+    else:
+        kernel_name = dev.extend_kernel_name()
 
-    nshare = world if args.shard == "samples" else 1
-    samples = W * H * frames_timed * nshare
+    samples = W * H * frames_job
     value = samples / dt / 1e6
 
+    steps_timed = (args.total_steps if args.total_steps > 0 else args.steps) * repeats
     if rank == 0:
-        ext_launches = max(st["extend_launches"], 1)
-        ext_ms = st["extend_ms"] / ext_launches
-        ext_bytes = extend_bytes(ctr0, accel) / ext_launches
-        ext_gbs = ext_bytes / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-        ext_rec = (ctr0["extend_node_visits"] + ctr0["extend_prim_tests"]) / (st["extend_ms"] * 1e-3) if st["extend_ms"] > 0 else 0.0
-        job_rec = (ctr["extend_node_visits"] + ctr["extend_prim_tests"] + ctr["connect_node_visits"] + ctr["connect_prim_tests"]) * nshare / dt / world   # per GPU
-        job_gbs = (extend_bytes(ctr, accel) + extend_bytes(ctr, accel, "connect")) * nshare / dt / world / 1e9   # per GPU, extend + connect of all lanes
-        traffic, traffic_note = None, "no PMC measurement committed for this configuration"
-        tpath = os.path.join(ROOT, "profiles", "extend_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                same = not args.model and tj.get("config", {}) == {"accel": args.accel, "detail": args.detail, "width": W, "height": H}
-                if same:
-                    traffic, traffic_note = tj.get("hbm_bytes_per_launch"), tj.get("source", "")
-            except Exception:
-                pass
+        ms_per_step = dt / max(frames_mine, 1) * 1e3             # per frame THIS GPU rendered (the job-level roofline's time base)
+        roof = {"bound": None, "kernel": "extend = " + kernel_name, "achieved": None, "peak": None, "unit": "GB/s", "frac": None, "traffic": None}
+        base_match = {"config": args.config, "accel": accel_name, "detail": args.detail, "width": W, "height": H, "model": bool(args.model)}
+        if dctr is not None and st2["extend_launches"] > 0:
+            e_launches = st2["extend_launches"]
+            e_s = st2["extend_ms"] * 1e-3 / e_launches          # the kernel's own average launch time: one context, nothing else on the GPU
+            alg = extend_bytes(dctr, accel) / e_launches
+            tr1 = load_traffic(dict(base_match, lanes=1))
+            lv, bound = ({}, None)
+            if tr1:
+                lv, bound = level_table(tr1["extend_bytes_per_launch"], e_s)
+            roof.update({
+                "timed": "ONE context with the GPU to itself: the %d extend launches of 16 frames, kernel-attached HIP events (hipExtLaunchKernelGGL); "
+                         "7 x avg_launch_ms <= the single-context frame time by construction" % e_launches,
+                "avg_launch_ms": round(e_s * 1e3, 5), "launches": e_launches,
+                "levels": lv, "bound": bound,
+                "achieved": lv[bound]["gbs"] if bound else None, "peak": lv[bound]["peak"] if bound else None,
+                "frac": lv[bound]["frac"] if bound else None,
+                "traffic": lv["hbm"]["bytes"] if "hbm" in lv else None,
+                "traffic_source": (tr1 or {}).get("source", "no committed PMC measurement matches this configuration (profiles/r03_traffic.json)"),
+                "algorithmic": {"bytes_per_launch": int(alg), "gbs": round(alg / e_s / 1e9, 1),
+                                "note": "SURVEY 8(d): R*48 + V_int*96 (+ TLAS / instance terms; BVH4: V4*160) + T_prim*52 from the device work counters, over the same "
+                                        "launch time: a throughput, NOT a fraction of HBM peak - the records are re-fetched from the vector L1s and L2s "
+                                        "(levels.*), so it may exceed the HBM peak"},
+                "per_ray": {"node_visits": round(dctr["extend_node_visits"] / max(dctr["extend_rays"], 1), 2),
+                            "prim_tests": round(dctr["extend_prim_tests"] / max(dctr["extend_rays"], 1), 2),
+                            "tlas_visits": round(dctr["extend_tlas_visits"] / max(dctr["extend_rays"], 1), 3)},
+            })
+            if st2["connect_launches"] > 0:
+                c_s = st2["connect_ms"] * 1e-3 / st2["connect_launches"]
+                c_alg = extend_bytes(dctr, accel, "connect") / st2["connect_launches"]
+                clv, cbound = level_table(tr1["connect_bytes_per_launch"], c_s) if tr1 and tr1.get("connect_bytes_per_launch") else ({}, None)
+                con = {"avg_launch_ms": round(c_s * 1e3, 5), "levels": clv, "bound": cbound, "frac": clv[cbound]["frac"] if cbound else None,
+                       "algorithmic_gbs": round(c_alg / c_s / 1e9, 1), "rays_per_launch": dctr["connect_rays"] // st2["connect_launches"],
+                       "note": "connect is an any-hit traversal with its own visit order; its node / triangle counters are its own work"}
+        # job level: every byte the PMC passes saw per frame (all kernels, all lanes) over the frame time of the timed region
+        trj = load_traffic(dict(base_match, lanes=lanes)) if args.shard == "samples" else None
+        job = {"ms_per_step": round(ms_per_step, 4), "lanes": lanes}
+        if trj:
+            jlv, jbound = level_table(trj["frame_bytes"], ms_per_step * 1e-3)
+            job.update({"levels": jlv, "bound": jbound, "frac": jlv[jbound]["frac"] if jbound else None, "traffic_source": trj.get("source", ""),
+                        "note": "bytes of ALL kernels of a frame (PMC passes of this configuration with %d lane(s)) over ms_per_step" % lanes})
+        job["algorithmic_gbs"] = round((extend_bytes(ctr, accel) + extend_bytes(ctr, accel, "connect")) / max(frames_mine, 1) / (ms_per_step * 1e-3) / 1e9, 1)
+        roof["job"] = job
+        if st_lane0["extend_launches"] > 0 and lanes > 1:
+            roof["lane0_launch_ms_while_sharing"] = round(st_lane0["extend_ms"] / st_lane0["extend_launches"], 5)   # diagnostic: NOT a kernel time (other lanes' kernels run beside it)
         traced = ctr["extend_rays"] + ctr["connect_rays"]
-        roof = {"bound": "hbm", "kernel": "extend = " + dev.extend_kernel_name(), "achieved": round(ext_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ext_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(ext_bytes), "avg_launch_ms": round(ext_ms, 5), "launches": st["extend_launches"],
-                "dram_frac": round(traffic / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and ext_ms > 0 else None,
-                "traffic_note": traffic_note,
-                "limiter": "memory latency + divergence of a dependent random-gather chain (vector L1 / L2 hits), not HBM bandwidth: `frac` is "
-                           "SURVEY 8(d)'s algorithmic bytes over the HBM peak and may exceed 1 because ~21 MB of node and triangle records "
-                           "are served from L1/L2/Infinity Cache; `dram_frac` is the measured DRAM-side traffic over the same peak; "
-                           "`gather` prices the kernel against what the chip sustains for its access pattern",
-                "gather": {"records_per_s": round(ext_rec, 0), "ceiling_records_per_s": GATHER_CEILING_RECORDS_PER_S,
-                           "frac": round(ext_rec / GATHER_CEILING_RECORDS_PER_S, 4),
-                           # a whole GPU's share of the job: every node and triangle record its lanes fetched in the timed region (extend + connect) over the wall time
-                           "job_records_per_s": round(job_rec, 0), "job_frac": round(job_rec / GATHER_CEILING_RECORDS_PER_S, 4),
-                           "note": "records = interior-node pair fetches + triangle-record fetches of all extend launches / their summed HIP-event "
-                                   "time; ceiling = tools/gather_probe.hip at the table size that matches the measured L1/L2 hit rates (<= 4 MB rows, "
-                                   "profiles/r02_gather_probe.log).  With lanes > 1 two contexts' launches overlap, so the per-launch rate is below "
-                                   "`single_stream` while the frame rate is higher"},
-                "single_stream": single,
-                "timed_context": "HIP events on the extend launches of lane 0 (of %d)" % len(group.devs),
-                # `achieved` / `frac` are per LAUNCH: a launch takes longer while other contexts' kernels share the GPU.  The
-                # job-level figure: algorithmic bytes of every extend and connect launch of all lanes over the wall time of the timed region
-                "job_algorithmic_gbs": round(job_gbs, 1), "job_algorithmic_frac": round(job_gbs / HBM_PEAK_GBS, 4),
-                "per_ray": {"node_visits": round(ctr["extend_node_visits"] / max(ctr["extend_rays"], 1), 2),
-                            "prim_tests": round(ctr["extend_prim_tests"] / max(ctr["extend_rays"], 1), 2)}}
         out = {
             "metric": "Mrays/sec + extend-kernel HBM GB/s, sponza 1080p 256spp",
             "value": round(value, 3), "unit": "Mrays/s (primary samples/s, reference definition renderer.cpp:60-62)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / frames_timed * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak" if args.shard == "samples" else "strong", "vs_baseline": None,
+            "n_gpus": world, "steps": args.total_steps if args.total_steps > 0 else args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(steps_timed, 1) * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"model {os.path.basename(args.model)}" if args.model else "sponza-class procedural atrium") +
-                                   f" ({len(sa.prims)} prims, SAH {args.accel.upper()}, "
-                                   f"{len(sa.bvh2)} nodes) {W}x{H}, NEE+cosine+RR+firefly, 7 bounces; step = 1 spp frame, "
-                                   f"{args.steps} spp timed per GPU (BASELINE config 3 = 256 spp) as {lanes} interleaved sample stream(s)",
-                       "shard": args.shard, "lanes": lanes, "contexts": len(ctx_plans), "triangles": int(len(sa.prims)), "extend_variant": args.extend_variant},
+            "config": {"workload": (f"model {os.path.basename(args.model)}" if args.model else f"BASELINE config {args.config}: " + conf["label"]) +
+                                   f" ({len(sa.prims)} prims, {accel_name.upper()}, {len(sa.bvh2)} BVH2 nodes, {len(sa.blas)} BLAS) {W}x{H}, "
+                                   f"{'NEE' if shading else 'Kajiya'}+cosine+RR+firefly, 7 bounces; step = 1 spp frame, "
+                                   + (f"a fixed {args.total_steps}-spp image split over the ranks" if args.total_steps > 0 else f"{args.steps} spp timed per GPU (config {args.config}: {conf['spp']} spp)")
+                                   + f", rendered as {lanes} interleaved sample stream(s) per GPU behind one rt_group handle",
+                       "baseline_config": args.config, "shard": args.shard, "lanes": lanes, "contexts": len(groups), "streams_concurrent": concurrency,
+                       "triangles": int(len(sa.prims)), "extend_variant": args.extend_variant},
             "repeats": repeats, "timed_s": round(dt, 4),
             "value_single_context": round(value_single, 3) if value_single else None,
             "rank_s": {"render": [round(x[0], 4) for x in per_rank], "all_reduce": [round(x[1], 5) for x in per_rank]},
-            "traced_mrays_per_s": round(traced * nshare / dt / 1e6, 2),
-            "rays_per_step": {"extend": ctr["extend_rays"] // frames_timed, "connect": ctr["connect_rays"] // frames_timed},
+            "traced_mrays_per_s": round(traced * (world if args.shard == "samples" else 1) / dt / 1e6, 2),
+            "rays_per_step": {"extend": ctr["extend_rays"] // max(frames_mine, 1), "connect": ctr["connect_rays"] // max(frames_mine, 1)},
             "roofline": roof, "connect_roofline": con, "stage_ms_per_step": stage_tab,
             "host_build_s": round(build_s, 2), "accum_rgb_sum": checksum,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(sa, cam, W, H, accel)
+            out["cpu_baseline"] = cpu_baseline(sa, cam, W, H, accel, shading)
         print(json.dumps(out), flush=True)
-    group.close()
-    if dev not in group.devs:
-        dev.close()
+    groups.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -387,12 +424,12 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(sa, cam, W, H, accel):
+def cpu_baseline(sa, cam, W, H, accel, shading=1):
     """The oracle (CPU restatement of the reference path, kind "port") timed on this box's host cores on a bounded
     sample of the same workload: full-resolution frames, row-band parallel over all cores."""
     from oracle.oracle_py import Oracle
     cores = usable_cores()
-    o = Oracle(sa, W, H, accel=accel)
+    o = Oracle(sa, W, H, accel=accel, shading=shading)
     t0 = time.perf_counter()
     o.render(cam, 1, threads=cores)
     t1 = time.perf_counter() - t0

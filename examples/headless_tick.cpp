@@ -61,73 +61,58 @@ int main(int argc, char** argv)
         else if (a == "--lanes" && i + 1 < argc) lanes = std::max(1, atoi(argv[++i]));
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
-    // HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, the null stream included) and serialises streams
-    // that share one: more than three lanes need more queues, and the variable has to be set before HIP initialises
-    if (lanes > 3) setenv("GPU_MAX_HW_QUEUES", "8", 0);
     try {
-        // One Renderer per lane.  Lane 0 alone is the reference's main loop; further lanes are independent sample streams of the same
-        // frame on the same GPU (own context and stream, the next slice of the host seed stream), ticked alternately so that the tails
-        // of one lane's launches are filled by the other's kernels (bench.py --lanes).
-        std::vector<std::unique_ptr<Renderer>> lane;
-        double buildMs = 0;
-        for (int m = 0; m < lanes; m++) {
-            lane.emplace_back(new Renderer(W, H));
-            Renderer& r = *lane.back();
-            Scene& s = r.scene;
-            // materials the way the reference's Scene constructor sets them up (scene.cpp:14-43)
-            { RtMaterial& mt = s.AddMaterial("white"); mt.color = RtFloat4{ 0.9f, 0.9f, 0.9f, 0 }; }
-            { RtMaterial& mt = s.AddMaterial("red"); mt.color = RtFloat4{ 0.9f, 0.15f, 0.1f, 0 }; }
-            { RtMaterial& mt = s.AddMaterial("green"); mt.color = RtFloat4{ 0.15f, 0.8f, 0.2f, 0 }; }
-            { RtMaterial& mt = s.AddMaterial("mirror"); mt.color = RtFloat4{ 0.9f, 0.9f, 0.9f, 0 }; mt.specular = 0.5f; }
-            { RtMaterial& mt = s.AddMaterial("light"); mt.color = RtFloat4{ 1, 1, 1, 0 }; mt.isLight = 1; mt.emittance = RtFloat4{ 40, 40, 40, 0 }; }
-            std::string floorMat = "white";
-            if (!tex.empty()) { s.LoadTexture(tex, "floor-texture"); floorMat = "floor-texture"; }
-            cornell_like(s, floorMat);
-            if (!obj.empty()) { const int n = s.LoadModel(obj, "white", float3(0, 0, 0), false); if (m == 0) printf("loaded %d triangles from %s\n", n, obj.c_str()); }
-            const auto t0 = std::chrono::steady_clock::now();
-            s.bvh2->BuildBLAS(true, 0);
-            if (m == 0) buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            r.imgui.bvh = bvh4 ? 1 : 0;
-            r.imgui.shading = kajiya ? 0 : 1;
-            r.camera.cam.origin = RtFloat4{ 0, 5, 14, 0 };
-            r.camera.cam.forward = RtFloat4{ 0, 0, 1, 0 };     // the camera looks along -forward
-            r.camera.cam.aperture = 0.0f;
-            r.camera.Fov(60);
-            r.Init();
-            // the lanes render the same scene: one device copy for all of them (Init uploaded one per Renderer; this one is dropped again)
-            if (m > 0 && rt_share_scene(r.ctx, lane[0]->ctx)) throw std::runtime_error(rt_last_error());
+        // ONE Renderer, as in the reference.  `lanes` > 1 makes it render the accumulation as that many interleaved sample streams
+        // (rt_group_*, include/rt355.h): Tick() then adds `lanes` frames to the accumulator, whose kernels
+        // overlap on the GPU.  The library arranges the hardware queues itself and says so on stderr if it could not.
+        Renderer r(W, H);
+        r.lanes = lanes;
+        Scene& s = r.scene;
+        // materials the way the reference's Scene constructor sets them up (scene.cpp:14-43)
+        { RtMaterial& mt = s.AddMaterial("white"); mt.color = RtFloat4{ 0.9f, 0.9f, 0.9f, 0 }; }
+        { RtMaterial& mt = s.AddMaterial("red"); mt.color = RtFloat4{ 0.9f, 0.15f, 0.1f, 0 }; }
+        { RtMaterial& mt = s.AddMaterial("green"); mt.color = RtFloat4{ 0.15f, 0.8f, 0.2f, 0 }; }
+        { RtMaterial& mt = s.AddMaterial("mirror"); mt.color = RtFloat4{ 0.9f, 0.9f, 0.9f, 0 }; mt.specular = 0.5f; }
+        { RtMaterial& mt = s.AddMaterial("light"); mt.color = RtFloat4{ 1, 1, 1, 0 }; mt.isLight = 1; mt.emittance = RtFloat4{ 40, 40, 40, 0 }; }
+        std::string floorMat = "white";
+        if (!tex.empty()) { s.LoadTexture(tex, "floor-texture"); floorMat = "floor-texture"; }
+        cornell_like(s, floorMat);
+        if (!obj.empty()) { const int n = s.LoadModel(obj, "white", float3(0, 0, 0), false); printf("loaded %d triangles from %s\n", n, obj.c_str()); }
+        const auto t0 = std::chrono::steady_clock::now();
+        s.bvh2->BuildBLAS(true, 0);
+        const double buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        r.imgui.bvh = bvh4 ? 1 : 0;
+        r.imgui.shading = kajiya ? 0 : 1;
+        r.camera.cam.origin = RtFloat4{ 0, 5, 14, 0 };
+        r.camera.cam.forward = RtFloat4{ 0, 0, 1, 0 };     // the camera looks along -forward
+        r.camera.cam.aperture = 0.0f;
+        r.camera.Fov(60);
+        r.Init();
+        if (decorrelate) {
+            // The reference seeds pixel i with the (i+1)-th output of ONE xorshift32 stream and then advances every pixel with the same
+            // xorshift32 (template.cpp:724-730, util.cl:50-56): neighbouring pixels draw the same numbers one step apart, which shows
+            // as horizontal streaks at low sample counts.  That is what parity reproduces by default; a caller who does not need
+            // parity hands over independent seeds (here the reference's own, unused, initSeed = WangHash((i + 1) * 17), util.cl:37-48).
             std::vector<uint32_t> seeds((size_t)W * H);
-            if (decorrelate) {
-                // The reference seeds pixel i with the (i+1)-th output of ONE xorshift32 stream and then advances every pixel with the same
-                // xorshift32 (template.cpp:724-730, util.cl:50-56): neighbouring pixels draw the same numbers one step apart, which shows
-                // as horizontal streaks at low sample counts.  That is what parity reproduces by default; a caller who does not need
-                // parity hands over independent seeds (here the reference's own, unused, initSeed = WangHash((i + 1) * 17), util.cl:37-48).
+            for (int m = 0; m < lanes; m++) {
                 for (size_t i = 0; i < seeds.size(); i++) {
                     uint32_t v = ((uint32_t)(i + (size_t)m * seeds.size()) + 1u) * 17u;
                     v = (v ^ 61u) ^ (v >> 16); v *= 9u; v = v ^ (v >> 4); v *= 0x27d4eb2du; v = v ^ (v >> 15);
                     seeds[i] = v ? v : 1u;
                 }
-                if (rt_set_seeds(r.ctx, seeds.data(), (int64_t)seeds.size())) throw std::runtime_error(rt_last_error());
-            } else if (m > 0) {   // lane m continues the reference's host seed stream where lane m-1 stopped (virtual rank m)
-                if (rth_seed_stream(seeds.data(), (int64_t)m * W * H, (int64_t)seeds.size()) || rt_set_seeds(r.ctx, seeds.data(), (int64_t)seeds.size()))
-                    throw std::runtime_error("seeding lane failed");
+                if (rt_set_seeds(rt_group_lane(r.group, m), seeds.data(), (int64_t)seeds.size())) throw std::runtime_error(rt_last_error());
             }
         }
         const auto t1 = std::chrono::steady_clock::now();
-        for (int i = 0; i < spp; i++) lane[(size_t)(i % lanes)]->Tick(0.016f);     // Tick() only enqueues: the lanes overlap on the GPU
-        Renderer& r = *lane[0];
-        std::vector<RtFloat4> sum((size_t)W * H), part((size_t)W * H);
-        r.ReadAccum(sum.data());                                                  // (synchronises lane 0)
-        for (int m = 1; m < lanes; m++) {                                         // the image is the sum of the lanes, in lane order
-            lane[(size_t)m]->ReadAccum(part.data());
-            for (size_t i = 0; i < sum.size(); i++) { sum[i].x += part[i].x; sum[i].y += part[i].y; sum[i].z += part[i].z; sum[i].w += part[i].w; }
-        }
+        const int ticks = (spp + lanes - 1) / lanes;                     // a Tick() is `lanes` frames
+        for (int i = 0; i < ticks; i++) r.Tick(0.016f);                  // Tick() only enqueues
+        r.ComputeEnergy();                                               // (reads the accumulator: synchronises)
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
-        if (lanes > 1) { if (rt_write_accum(r.ctx, sum.data())) throw std::runtime_error(rt_last_error()); r.settings->frames = spp + 1; }
-        r.ComputeEnergy();
         r.SaveFrame(out.c_str());
-        printf("headless_tick: %zu primitives, BVH build %.1f ms, %d spp at %dx%d in %.1f ms (%.1f M samples/s, %d lane%s), energy %.6g, wrote %s\n",
-               r.scene.primitives.size(), buildMs, spp, W, H, ms, (double)W * H * spp / ms / 1e3, lanes, lanes > 1 ? "s" : "", (double)r.energy_total, out.c_str());
+        const int done = ticks * lanes;
+        printf("headless_tick: %zu primitives, BVH build %.1f ms, %d spp at %dx%d in %.1f ms (%.1f M samples/s, %d lane%s, %d concurrent), energy %.6g, wrote %s\n",
+               r.scene.primitives.size(), buildMs, done, W, H, ms, (double)W * H * done / ms / 1e3, lanes, lanes > 1 ? "s" : "",
+               rt_group_concurrency(r.group), (double)r.energy_total, out.c_str());
     } catch (const std::exception& e) {
         fprintf(stderr, "headless_tick: %s\n", e.what());
         return 1;

@@ -108,12 +108,53 @@ int rt_upload_scene(RtCtx* ctx,
                     const RtTLASNode* tlas, int32_t nTlas,
                     const RtBVHInstance* blas, int32_t nBlas);
 
+/* The host-side shape checks rt_upload_scene runs before it touches the device (index ranges, tree cycles and depths, stack needs,
+ * the 32768-node / instance bound of the TLAS encodings), callable without a GPU.  `accel` says how bvhNodes is to be read. */
+int rt_validate_scene(int32_t accel,
+                      const RtPrimitive* prims, int32_t nPrims, const RtMaterial* mats, int32_t nMats,
+                      const RtFloat4* textures, int32_t nTexels, const uint32_t* lights, int32_t nLights,
+                      const void* bvhNodes, int32_t nNodes, const uint32_t* primIdx, int32_t nIdx,
+                      const RtTLASNode* tlas, int32_t nTlas, const RtBVHInstance* blas, int32_t nBlas);
+
 /* A second context on the same device renders the scene `from` holds: it takes `from`'s device copy (uploaded arrays + derived
  * layouts) instead of uploading its own - one copy in HBM and in the caches for the sample streams of a GPU or the row bands of a
  * frame.  The contexts must agree in accel and extend_variant; the copy lives until the last context holding it is destroyed or
  * uploads another scene.  (The reference has one Renderer and one set of buffers, renderer.cpp:160-208; several contexts per device
  * are this library's way to keep a GPU full.) */
 int rt_share_scene(RtCtx* ctx, RtCtx* from);
+
+/* ---- lanes: one accumulation as several interleaved sample streams behind one handle -------------------------------------------
+ * What stands behind Renderer::Tick() (renderer.cpp:26-63) when a GPU is to be kept full: `lanes` contexts (own HIP stream, queues,
+ * accumulator, seed slice) that share ONE device copy of the scene; their frames are queued interleaved so that the tails of one
+ * lane's launches are filled by the others' kernels (1 lane: 733, 4 lanes: 1,000 M samples/s on the bench scene).  Lane m renders
+ * sample stream firstStream + m (seeds = that slice of the reference's host xorshift32 stream, renderer.cpp:195-196); the group's
+ * accumulator is the sum of the lanes' accumulators in lane order and, after k frames in all, holds k samples per pixel - prep()
+ * divides by k exactly as with one stream (postproc.cl:71).  A group of ONE lane is the reference's single Renderer bit for bit.
+ * HIP runs kernels of streams that share a hardware queue one after the other: the library asks for GPU_MAX_HW_QUEUES=8 when it is
+ * loaded (effective if HIP has not been initialised yet), rt_group_create measures how many of the group's streams really run side
+ * by side (rt_group_concurrency) and writes one line to stderr when that is fewer than `lanes`. */
+typedef struct RtGroup RtGroup;
+int rt_group_create(const RtConfig* cfg, int32_t lanes, RtGroup** out);      /* lanes 1..8; cfg as for rt_create (row band included)   */
+int rt_group_destroy(RtGroup* g);
+int rt_group_lanes(RtGroup* g);
+int rt_group_concurrency(RtGroup* g);                                        /* streams measured to run concurrently at creation        */
+RtCtx* rt_group_lane(RtGroup* g, int32_t m);                                 /* lane m's context (counters, stage times, debug stages)  */
+uint64_t rt_group_frames(RtGroup* g);                                        /* frames rendered by all lanes since the last reset       */
+int rt_group_upload_scene(RtGroup* g,
+                          const RtPrimitive* prims, int32_t nPrims, const RtMaterial* mats, int32_t nMats,
+                          const RtFloat4* textures, int32_t nTexels, const uint32_t* lights, int32_t nLights,
+                          const void* bvhNodes, int32_t nNodes, const uint32_t* primIdx, int32_t nIdx,
+                          const RtTLASNode* tlas, int32_t nTlas, const RtBVHInstance* blas, int32_t nBlas);
+int rt_group_share_scene(RtGroup* g, RtGroup* from);                         /* e.g. the row bands of one frame: one device copy        */
+int rt_group_seed(RtGroup* g, uint64_t firstStream);                         /* a single Renderer: 0; rank r of a sample split: r*lanes */
+int rt_group_reset(RtGroup* g);                                              /* resetKernel on every lane; frames = 0                   */
+int rt_group_render(RtGroup* g, const RtCamera* cam, const RtSettings* settings, int32_t frames);   /* `frames` in all, round-robin   */
+int rt_group_synchronize(RtGroup* g);
+int rt_group_sum(RtGroup* g, void* devicePtr);                               /* lane-ordered sum of the group's rows into devicePtr (a
+                                                                              * full-frame float4 buffer; NULL: the group's own)       */
+int rt_group_read_accum(RtGroup* g, RtFloat4* out);
+int rt_group_focus(RtGroup* g, int32_t x, int32_t y, const RtCamera* cam, float* t);
+int rt_group_postproc(RtGroup* g, int32_t frames, float vignette, float gamma, float chromatic, RtFloat4* outF32, uint8_t* outRGBA8);
 
 /* seedBuffer (renderer.cpp:195-196,200).  rt_set_seeds takes the band's slice
  * (one uint per band pixel); rt_seed_default fills seeds[i] with the (firstPixel+i+1)-th

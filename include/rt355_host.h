@@ -86,6 +86,7 @@ int  rth_renderer_save_frame(RthRenderer* r, const char* file);
 int  rth_renderer_camera_move(RthRenderer* r, int camdir /* 0 Forward 1 Backwards 2 Left 3 Right 4 Up 5 Down */);
 int  rth_renderer_camera_mouse(RthRenderer* r, float xOffset, float yOffset);
 int  rth_renderer_camera_zoom(RthRenderer* r, float offset);
+int rth_renderer_set_lanes(RthRenderer* r, int lanes);   /* before rth_renderer_init: Renderer::lanes (Tick = `lanes` overlapping frames) */
 int  rth_renderer_frames(RthRenderer* r);                                 /* settings->frames */          /* Renderer::SaveFrame (renderer.cpp:303-308) */
 
 #ifdef __cplusplus

@@ -65,7 +65,10 @@ DEVICE_SYMBOLS = [
     "rt_get_seeds", "rt_bind_accum", "rt_accum_device_ptr", "rt_stream", "rt_reset", "rt_render", "rt_synchronize", "rt_focus",
     "rt_read_accum", "rt_write_accum", "rt_postproc", "rt_read_counters", "rt_reset_counters", "rt_read_stage_times", "rt_reset_stage_times", "rt_set_profile",
     "rt_stage_begin_frame", "rt_stage_generate", "rt_stage_extend", "rt_stage_shade", "rt_stage_connect",
-    "rt_debug_get_rays", "rt_debug_set_rays", "rt_debug_get_shadow", "rt_debug_enable_steps", "rt_debug_get_steps"]
+    "rt_debug_get_rays", "rt_debug_set_rays", "rt_debug_get_shadow", "rt_debug_enable_steps", "rt_debug_get_steps", "rt_validate_scene",
+    "rt_group_create", "rt_group_destroy", "rt_group_lanes", "rt_group_concurrency", "rt_group_lane", "rt_group_frames", "rt_group_upload_scene", "rt_group_share_scene",
+    "rt_group_seed", "rt_group_reset", "rt_group_render", "rt_group_synchronize", "rt_group_sum", "rt_group_read_accum", "rt_group_focus",
+    "rt_group_postproc"]
 HOST_SYMBOLS = [
     "rth_last_error", "rth_scene_create", "rth_scene_destroy", "rth_add_material", "rth_add_texture", "rth_load_texture", "rth_add_sphere",
     "rth_add_plane", "rth_add_triangle", "rth_add_quad", "rth_add_triangles", "rth_build_blas", "rth_build_bvh4",
@@ -73,7 +76,7 @@ HOST_SYMBOLS = [
     "rth_bvh2_nodes", "rth_bvh4_nodes", "rth_prim_idx", "rth_tlas_nodes", "rth_blas_nodes", "rth_bvh_stats", "rth_camera",
     "rth_renderer_create", "rth_renderer_destroy", "rth_renderer_init", "rth_renderer_set_camera", "rth_renderer_tick",
     "rth_renderer_read", "rth_renderer_camera", "rth_seed_stream", "rth_load_model", "rth_save_png",
-    "rth_set_build_threads", "rth_renderer_save_frame", "rth_renderer_camera_move", "rth_renderer_camera_mouse", "rth_renderer_camera_zoom", "rth_renderer_frames"]
+    "rth_set_build_threads", "rth_renderer_save_frame", "rth_renderer_camera_move", "rth_renderer_camera_mouse", "rth_renderer_camera_zoom", "rth_renderer_frames", "rth_renderer_set_lanes"]
 
 _dev = None
 _host = None
@@ -134,6 +137,25 @@ def device_lib():
         lib.rt_debug_get_shadow.argtypes = [vp, i32, i32, vp, i32, C.POINTER(i32)]
         lib.rt_debug_get_steps.argtypes = [vp, vp, i32, C.POINTER(i32)]
         lib.rt_debug_enable_steps.argtypes = [vp, i32]
+        lib.rt_validate_scene.argtypes = [i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32]
+        lib.rt_group_create.argtypes = [vp, i32, C.POINTER(vp)]
+        lib.rt_group_destroy.argtypes = [vp]
+        lib.rt_group_lanes.argtypes = [vp]
+        lib.rt_group_concurrency.argtypes = [vp]
+        lib.rt_group_lane.argtypes = [vp, i32]
+        lib.rt_group_lane.restype = vp
+        lib.rt_group_frames.argtypes = [vp]
+        lib.rt_group_frames.restype = C.c_uint64
+        lib.rt_group_upload_scene.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32]
+        lib.rt_group_seed.argtypes = [vp, C.c_uint64]
+        lib.rt_group_share_scene.argtypes = [vp, vp]
+        lib.rt_group_reset.argtypes = [vp]
+        lib.rt_group_render.argtypes = [vp, vp, vp, i32]
+        lib.rt_group_synchronize.argtypes = [vp]
+        lib.rt_group_sum.argtypes = [vp, vp]
+        lib.rt_group_read_accum.argtypes = [vp, vp]
+        lib.rt_group_focus.argtypes = [vp, i32, i32, vp, C.POINTER(C.c_float)]
+        lib.rt_group_postproc.argtypes = [vp, i32, C.c_float, C.c_float, C.c_float, vp, vp]
         _dev = lib
     return _dev
 
@@ -184,6 +206,7 @@ def host_lib():
         lib.rth_renderer_camera_mouse.argtypes = [vp, C.c_float, C.c_float]
         lib.rth_renderer_camera_zoom.argtypes = [vp, C.c_float]
         lib.rth_renderer_frames.argtypes = [vp]
+        lib.rth_renderer_set_lanes.argtypes = [vp, i32]
         _host = lib
     return _host
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -56,7 +57,7 @@ struct RtCtx {
     struct Ev { hipEvent_t a, b; int stage; };
     std::vector<Ev> evPool; size_t evUsed = 0;
     RtStageTimes times{};
-    int maxDepth2 = 0;
+    int maxDepth2 = 0, tlasDepth = 0;
     int layout = 0;   // 0 = traverse the reference arrays as uploaded, 1 = derived pair/triangle-record layout
     bool persist = false;   // persistent-wavefront traversal (layout 1, single BLAS)
     bool persist4 = false;  // ... over the BVH4
@@ -313,17 +314,22 @@ static int bvh4_stack_need(const RtBVHNode4* n, int32_t nNodes, uint32_t root)
     return best;
 }
 
-extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPrims, const RtMaterial* mats, int32_t nMats,
-                               const RtFloat4* textures, int32_t nTexels, const uint32_t* lights, int32_t nLights,
-                               const void* bvhNodes, int32_t nNodes, const uint32_t* primIdx, int32_t nIdx,
-                               const RtTLASNode* tlas, int32_t nTlas, const RtBVHInstance* blas, int32_t nBlas)
+// Host-side shape checks of a scene (no device needed; rt_upload_scene runs them first): a kernel that walks a malformed tree can
+// fault the GPU.  Also sizes the LDS traversal stack and the texture padding.
+static int validate_scene(int accel, const RtPrimitive* prims, int32_t nPrims, const RtMaterial* mats, int32_t nMats,
+                          const RtFloat4* textures, int32_t nTexels, const uint32_t* lights, int32_t nLights,
+                          const void* bvhNodes, int32_t nNodes, const uint32_t* primIdx, int32_t nIdx,
+                          const RtTLASNode* tlas, int32_t nTlas, const RtBVHInstance* blas, int32_t nBlas,
+                          int* stackEntriesOut, int64_t* texPadOut, int* tlasDepthOut)
 {
-    if (!ctx) return fail(RT_E_INVALID, "rt_upload_scene: null context");
+    if (accel != RT_ACCEL_BVH2 && accel != RT_ACCEL_BVH4) return fail(RT_E_INVALID, "rt_upload_scene: unknown accel %d", accel);
     if (!prims || nPrims <= 0 || !mats || nMats <= 0 || !bvhNodes || nNodes <= 0 || !primIdx || nIdx <= 0 || !tlas || nTlas <= 0 || !blas || nBlas <= 0)
         return fail(RT_E_INVALID, "rt_upload_scene: missing array (prims/materials/bvh/primIdx/tlas/blas are required)");
     if (nLights > 0 && !lights) return fail(RT_E_INVALID, "rt_upload_scene: nLights > 0 but lights == NULL");
     if (nTexels > 0 && !textures) return fail(RT_E_INVALID, "rt_upload_scene: nTexels > 0 but textures == NULL");
-    // Host-side shape checks: a kernel that walks a malformed tree can fault the GPU.
+    // Child ids and instance ids of the TLAS travel as 15-bit values on the traversal stacks (bit 15 = leaf; the reference's own
+    // TLASNode packs two 16-bit child ids into leftRight and TLAS::Build stops at 256 instances, tlas.cpp:11): larger trees are refused.
+    if (nTlas > 0x8000 || nBlas > 0x8000) return fail(RT_E_UNSUPPORTED, "rt_upload_scene: %d TLAS nodes / %d instances exceed the 32768 the traversal stacks encode", nTlas, nBlas);
     for (int32_t i = 0; i < nPrims; i++) {
         if (prims[i].matIdx < 0 || prims[i].matIdx >= nMats) return fail(RT_E_INVALID, "primitive %d: matIdx %d out of range", i, prims[i].matIdx);
         if (prims[i].objType < 0 || prims[i].objType > 2) return fail(RT_E_INVALID, "primitive %d: objType %d", i, prims[i].objType);
@@ -342,18 +348,19 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         if (lr == 0) { if (tlas[i].BLASidx >= (uint32_t)nBlas) return fail(RT_E_INVALID, "tlas node %d: BLASidx out of range", i); }
         else if ((lr & 0xffffu) >= (uint32_t)nTlas || (lr >> 16) >= (uint32_t)nTlas) return fail(RT_E_INVALID, "tlas node %d: child out of range", i);
     }
+    int tlasDepth = 0;
     {   // walk the TLAS from node 0: a back reference would make traverse_tlas spin forever, and its private stack holds
         // RT_TLAS_STACK entries (the ordered descent keeps at most one pending sibling per level, so depth bounds the stack)
         std::vector<std::pair<uint32_t, int>> st; st.push_back({ 0u, 0 });
-        size_t visited = 0; int depth = 0;
+        size_t visited = 0;
         while (!st.empty()) {
             auto [i, d] = st.back(); st.pop_back();
             if (++visited > (size_t)nTlas) return fail(RT_E_INVALID, "tlas: a node is reachable twice (cycle or shared child)");
-            depth = std::max(depth, d);
+            tlasDepth = std::max(tlasDepth, d);
             const uint32_t lr = tlas[i].leftRight;
             if (lr != 0) { st.push_back({ lr & 0xffffu, d + 1 }); st.push_back({ lr >> 16, d + 1 }); }
         }
-        if (depth > RT_TLAS_STACK) return fail(RT_E_UNSUPPORTED, "tlas: depth %d exceeds the %d-entry traversal stack", depth, RT_TLAS_STACK);
+        if (tlasDepth > RT_TLAS_STACK) return fail(RT_E_UNSUPPORTED, "tlas: depth %d exceeds the %d-entry traversal stack", tlasDepth, RT_TLAS_STACK);
     }
     // The reference kernels give BVH2 32 and BVH4 64 stack entries (bvh.cl:15,57) and overflow silently beyond that
     // (SBVH trees at alpha = 0 do get deeper than 32); this library sizes the LDS stack to the tree, up to 64 entries.
@@ -361,14 +368,13 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
     int stackNeed = 1;
     for (int32_t b = 0; b < nBlas; b++) {
         if (blas[b].bvhIdx >= (uint32_t)nNodes) return fail(RT_E_INVALID, "instance %d: bvhIdx out of range", b);
-        int need = ctx->cfg.accel == RT_ACCEL_BVH4 ? bvh4_stack_need((const RtBVHNode4*)bvhNodes, nNodes, blas[b].bvhIdx)
-                                                   : bvh2_depth((const RtBVHNode2*)bvhNodes, nNodes, blas[b].bvhIdx);
+        int need = accel == RT_ACCEL_BVH4 ? bvh4_stack_need((const RtBVHNode4*)bvhNodes, nNodes, blas[b].bvhIdx)
+                                          : bvh2_depth((const RtBVHNode2*)bvhNodes, nNodes, blas[b].bvhIdx);
         if (need < 0) return fail(RT_E_INVALID, "instance %d: malformed BVH (child index out of range or cycle)", b);
         if (need > stackCap) return fail(RT_E_UNSUPPORTED, "instance %d: traversal needs %d stack entries, at most %d are supported", b, need, stackCap);
         stackNeed = std::max(stackNeed, need);
     }
-    ctx->stackEntries = std::min(stackCap, std::max(stackNeed + 1, 6)); // >= 6: flush_counters reuses 20 words of it
-    if (ctx->cfg.accel == RT_ACCEL_BVH2) {
+    if (accel == RT_ACCEL_BVH2) {
         const RtBVHNode2* n2 = (const RtBVHNode2*)bvhNodes;
         for (int32_t i = 0; i < nNodes; i++) if (n2[i].count > 0 && (uint64_t)n2[i].first + n2[i].count > (uint64_t)nIdx)
             return fail(RT_E_INVALID, "bvh node %d: leaf range exceeds primIdx", i);
@@ -376,6 +382,32 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         const RtBVHNode4* n4 = (const RtBVHNode4*)bvhNodes;
         for (int32_t i = 0; i < nNodes; i++) for (int k = 0; k < 4; k++) if (n4[i].first[k] != RT_INVALID && n4[i].count[k] > 0 &&
             (int64_t)n4[i].first[k] + n4[i].count[k] > (int64_t)nIdx) return fail(RT_E_INVALID, "bvh4 node %d: leaf range exceeds primIdx", i);
+    }
+    if (stackEntriesOut) *stackEntriesOut = std::min(stackCap, std::max(stackNeed + 1, 6)); // >= 6: flush_counters reuses 20 words of it
+    if (texPadOut) *texPadOut = texPad;
+    if (tlasDepthOut) *tlasDepthOut = tlasDepth;
+    return RT_OK;
+}
+extern "C" int rt_validate_scene(int32_t accel, const RtPrimitive* prims, int32_t nPrims, const RtMaterial* mats, int32_t nMats,
+                                 const RtFloat4* textures, int32_t nTexels, const uint32_t* lights, int32_t nLights,
+                                 const void* bvhNodes, int32_t nNodes, const uint32_t* primIdx, int32_t nIdx,
+                                 const RtTLASNode* tlas, int32_t nTlas, const RtBVHInstance* blas, int32_t nBlas)
+{
+    return validate_scene(accel, prims, nPrims, mats, nMats, textures, nTexels, lights, nLights, bvhNodes, nNodes, primIdx, nIdx, tlas, nTlas, blas, nBlas,
+                          nullptr, nullptr, nullptr);
+}
+
+extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPrims, const RtMaterial* mats, int32_t nMats,
+                               const RtFloat4* textures, int32_t nTexels, const uint32_t* lights, int32_t nLights,
+                               const void* bvhNodes, int32_t nNodes, const uint32_t* primIdx, int32_t nIdx,
+                               const RtTLASNode* tlas, int32_t nTlas, const RtBVHInstance* blas, int32_t nBlas)
+{
+    if (!ctx) return fail(RT_E_INVALID, "rt_upload_scene: null context");
+    int stackEntries = RT_BVH2_STACK, tlasDepth = 0; int64_t texPad = 2;
+    {   // nothing of the context changes until the arrays have passed (a failed upload leaves the bound scene usable)
+        const int vrc = validate_scene(ctx->cfg.accel, prims, nPrims, mats, nMats, textures, nTexels, lights, nLights, bvhNodes, nNodes, primIdx, nIdx,
+                                       tlas, nTlas, blas, nBlas, &stackEntries, &texPad, &tlasDepth);
+        if (vrc != RT_OK) return vrc;
     }
     HIPCHK(hipSetDevice(ctx->cfg.device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -572,6 +604,7 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
     sc.nLights = nLights; sc.nPrims = nPrims; sc.nBlas = nBlas; sc.nTex = nTexels;
     ctx->singleBlas = tlas[0].leftRight == 0;
     ctx->sc = sc;
+    ctx->stackEntries = stackEntries; ctx->tlasDepth = tlasDepth;
     rc = configure_traversal(ctx);
     if (rc != RT_OK) { ctx->scene.reset(); return rc; }
     ctx->sceneLoaded = true;
@@ -633,7 +666,7 @@ extern "C" int rt_share_scene(RtCtx* ctx, RtCtx* from)
     ctx->sceneLoaded = false;
     ctx->scene = from->scene;
     ctx->sc = from->sc;
-    ctx->layout = from->layout; ctx->maxDepth2 = from->maxDepth2; ctx->stackEntries = from->stackEntries; ctx->singleBlas = from->singleBlas;
+    ctx->layout = from->layout; ctx->maxDepth2 = from->maxDepth2; ctx->stackEntries = from->stackEntries; ctx->singleBlas = from->singleBlas; ctx->tlasDepth = from->tlasDepth;
     const int rc = configure_traversal(ctx);
     if (rc != RT_OK) { ctx->scene.reset(); return rc; }
     ctx->sceneLoaded = true;
@@ -1068,6 +1101,238 @@ extern "C" int rt_postproc(RtCtx* ctx, int32_t frames, float vignette, float gam
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ev_collect(ctx);
     return RT_OK;
+}
+
+// ---- lanes: several sample streams of one accumulation behind ONE handle -------------------------------------------------------
+// Every launch of a frame ends in a tail of a few long rays during which most of the chip idles, and the frames of ONE seed stream cannot
+// overlap (each continues the RNG state of the one before).  A group renders the accumulation as `lanes` independent sample streams
+// instead - own context, HIP stream, queues and seed slice each, ONE device copy of the scene - and interleaves their frames, so the
+// tails of one lane's launches are filled by the others' kernels.  The group's accumulator is the sum of its lanes' accumulators in
+// lane order.  (Reference: one Renderer, one in-order queue, renderer.cpp:26-94; the group is what stands behind Renderer::Tick here.)
+//
+// HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, the null stream included) and runs kernels of streams
+// that share one after the other.  The library asks for 8 when it is loaded (before HIP initialises, unless the application already
+// did), and rt_group_create MEASURES how many of its streams really run side by side, so a caller is told instead of silently serialised.
+__attribute__((constructor)) static void rt355_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
+__global__ void k_spin(long long ticks, int* sink)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (ticks < 0) *sink = 1;
+}
+__global__ __launch_bounds__(kBlock) void k_sum_lanes(float4* out, const float4* a0, const float4* a1, const float4* a2, const float4* a3,
+                                                       const float4* a4, const float4* a5, const float4* a6, const float4* a7, int lanes, int first, int n)
+{
+    // only the group's own rows [first, first + n): the bands of one frame can be summed into one buffer without touching each other
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    i += first;
+    const float4* a[8] = { a0, a1, a2, a3, a4, a5, a6, a7 };
+    float4 s = a[0][i];
+    for (int m = 1; m < lanes; m++) s = add4(s, a[m][i]);   // lane order, left to right
+    out[i] = s;
+}
+
+struct RtGroup {
+    std::vector<RtCtx*> lane;
+    float4* sum = nullptr;              // lane-ordered sum of the lanes' accumulators (own buffer)
+    std::vector<hipEvent_t> done;       // one per lane: "this lane's queued frames are finished", for the sum on lane 0's stream
+    uint64_t frames = 0;                // frames rendered by all lanes since the last reset (= the divisor of prep())
+    int concurrent = 0;                 // streams measured to run side by side at creation
+    int nextLane = 0;                   // round-robin position, so that successive one-frame calls visit all lanes
+};
+static constexpr int kMaxLanes = 8;
+
+static void group_free(RtGroup* g)
+{
+    if (!g) return;
+    for (RtCtx* c : g->lane) ctx_free(c);
+    for (hipEvent_t e : g->done) (void)hipEventDestroy(e);
+    if (g->sum) (void)hipFree(g->sum);
+    delete g;
+}
+// How many of the group's streams execute concurrently: one single-wave kernel that naps for ~200 us on every stream at once.
+static int measure_concurrency(RtGroup* g)
+{
+    const int n = (int)g->lane.size();
+    if (n <= 1) return n;
+    int rate = 0;
+    if (hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, g->lane[0]->cfg.device) != hipSuccess || rate <= 0) rate = 100000;   // kHz
+    const long long ticks = (long long)rate / 5;   // 200 us
+    int* sink = (int*)g->lane[0]->q.fault;          // never written (ticks >= 0)
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0;
+    float one = 0, all = 0;
+    for (int pass = 0; pass < 2; pass++) {   // pass 0 warms the code object up
+        (void)hipEventRecord(a, g->lane[0]->stream);
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, g->lane[0]->stream, ticks, sink);
+        (void)hipEventRecord(b, g->lane[0]->stream);
+        (void)hipEventSynchronize(b);
+        (void)hipEventElapsedTime(&one, a, b);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (RtCtx* c : g->lane) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->stream, ticks, sink);
+    for (RtCtx* c : g->lane) (void)hipStreamSynchronize(c->stream);
+    all = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (one <= 0 || all <= 0) return 0;
+    const float rounds = std::max(1.0f, all / one);          // serialised streams take n naps, concurrent ones a little over one
+    return std::max(1, std::min(n, (int)std::lround((float)n / rounds)));
+}
+
+extern "C" int rt_group_create(const RtConfig* cfg, int32_t lanes, RtGroup** out)
+{
+    if (!cfg || !out) return fail(RT_E_INVALID, "rt_group_create: null argument");
+    if (lanes < 1 || lanes > kMaxLanes) return fail(RT_E_INVALID, "rt_group_create: lanes must be 1..%d", kMaxLanes);
+    std::unique_ptr<RtGroup, void (*)(RtGroup*)> guard(new RtGroup(), group_free);
+    RtGroup* g = guard.get();
+    for (int m = 0; m < lanes; m++) {
+        RtConfig c = *cfg;
+        if (lanes > 1) {   // contexts that share the GPU get the footprints that fit BESIDE each other
+            if (c.shade_blocks_per_cu == 0) c.shade_blocks_per_cu = 1;
+            if (c.persist_blocks_per_cu == 0) c.persist_blocks_per_cu = 2;
+        }
+        if (m > 0) c.profile = 0;   // HIP-event brackets on the first lane only
+        RtCtx* ctx = nullptr;
+        const int rc = rt_create(&c, &ctx);
+        if (rc != RT_OK) return rc;
+        g->lane.push_back(ctx);
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(RT_E_DEVICE, "rt_group_create: hipEventCreate failed");
+        g->done.push_back(e);
+    }
+    const size_t px = (size_t)cfg->width * cfg->height;
+    if (hipMalloc((void**)&g->sum, px * sizeof(float4)) != hipSuccess) return fail(RT_E_NOMEM, "rt_group_create: hipMalloc of the group accumulator failed");
+    HIPCHK(hipMemset(g->sum, 0, px * sizeof(float4)));
+    g->concurrent = measure_concurrency(g);
+    if (g->concurrent < lanes) {
+        static bool warned = false;
+        if (!warned) {
+            warned = true;
+            fprintf(stderr, "librt355: %d lanes requested but only %d of their HIP streams run concurrently (GPU_MAX_HW_QUEUES=%s; HIP serialises streams that "
+                            "share a hardware queue - set GPU_MAX_HW_QUEUES >= lanes + 1 before the process initialises HIP, or load librt355 first)\n",
+                    lanes, g->concurrent, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "unset");
+        }
+    }
+    *out = guard.release();
+    return RT_OK;
+}
+extern "C" int rt_group_destroy(RtGroup* g) { group_free(g); return RT_OK; }
+extern "C" int rt_group_lanes(RtGroup* g) { return g ? (int)g->lane.size() : 0; }
+extern "C" int rt_group_concurrency(RtGroup* g) { return g ? g->concurrent : 0; }
+extern "C" RtCtx* rt_group_lane(RtGroup* g, int32_t m) { return g && m >= 0 && m < (int)g->lane.size() ? g->lane[(size_t)m] : nullptr; }
+extern "C" uint64_t rt_group_frames(RtGroup* g) { return g ? g->frames : 0; }
+
+extern "C" int rt_group_upload_scene(RtGroup* g, const RtPrimitive* prims, int32_t nPrims, const RtMaterial* mats, int32_t nMats,
+                                     const RtFloat4* textures, int32_t nTexels, const uint32_t* lights, int32_t nLights,
+                                     const void* bvhNodes, int32_t nNodes, const uint32_t* primIdx, int32_t nIdx,
+                                     const RtTLASNode* tlas, int32_t nTlas, const RtBVHInstance* blas, int32_t nBlas)
+{
+    if (!g) return fail(RT_E_INVALID, "rt_group_upload_scene: null group");
+    int rc = rt_upload_scene(g->lane[0], prims, nPrims, mats, nMats, textures, nTexels, lights, nLights, bvhNodes, nNodes, primIdx, nIdx, tlas, nTlas, blas, nBlas);
+    for (size_t m = 1; m < g->lane.size() && rc == RT_OK; m++) rc = rt_share_scene(g->lane[m], g->lane[0]);   // ONE device copy
+    return rc;
+}
+// Another group on the same device (e.g. another row band of the frame) renders from the device copy `from` holds.
+extern "C" int rt_group_share_scene(RtGroup* g, RtGroup* from)
+{
+    if (!g || !from) return fail(RT_E_INVALID, "rt_group_share_scene: null group");
+    for (RtCtx* c : g->lane) { const int rc = rt_share_scene(c, from->lane[0]); if (rc != RT_OK) return rc; }
+    return RT_OK;
+}
+// Lane m renders sample stream `firstStream + m`: its seeds are outputs (firstStream + m) * W*H + firstPixel + i + 1 of the reference's
+// host xorshift32 stream (renderer.cpp:195-196).  A single Renderer has firstStream 0; rank r of a sample-partitioned job r * lanes.
+extern "C" int rt_group_seed(RtGroup* g, uint64_t firstStream)
+{
+    if (!g) return fail(RT_E_INVALID, "rt_group_seed: null group");
+    const RtCtx* c0 = g->lane[0];
+    const uint64_t P = (uint64_t)c0->cfg.width * (uint64_t)c0->cfg.height;
+    uint32_t x = 0x12345678u; // template/template.cpp:711
+    auto next = [&x]() { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; };
+    uint64_t pos = 0;
+    std::vector<uint32_t> s((size_t)c0->nPix);
+    for (size_t m = 0; m < g->lane.size(); m++) {
+        const uint64_t first = (firstStream + m) * P + (uint64_t)c0->firstPixel;
+        for (; pos < first; pos++) next();
+        for (auto& v : s) v = next();
+        pos += s.size();
+        const int rc = rt_set_seeds(g->lane[m], s.data(), (int64_t)s.size());
+        if (rc != RT_OK) return rc;
+    }
+    return RT_OK;
+}
+extern "C" int rt_group_reset(RtGroup* g)
+{
+    if (!g) return fail(RT_E_INVALID, "rt_group_reset: null group");
+    for (RtCtx* c : g->lane) { const int rc = rt_reset(c); if (rc != RT_OK) return rc; }
+    g->frames = 0; g->nextLane = 0;
+    return RT_OK;
+}
+// `frames` frames in all, dealt to the lanes round-robin (continuing where the last call stopped) and queued interleaved, so that the
+// lanes' kernels overlap on the GPU.  Asynchronous.  After k frames in total the group accumulator holds the sum of k samples per
+// pixel: prep() divides by k (postproc.cl:71), exactly as with one stream.
+extern "C" int rt_group_render(RtGroup* g, const RtCamera* cam, const RtSettings* settings, int32_t frames)
+{
+    if (!g || !cam) return fail(RT_E_INVALID, "rt_group_render: null argument");
+    if (frames <= 0) return fail(RT_E_INVALID, "rt_group_render: frames must be > 0");
+    const int n = (int)g->lane.size();
+    for (int f = 0; f < frames; f++) {
+        const int rc = rt_render(g->lane[(size_t)g->nextLane], cam, settings, 1);
+        if (rc != RT_OK) return rc;
+        g->nextLane = (g->nextLane + 1) % n;
+    }
+    g->frames += (uint64_t)frames;
+    return RT_OK;
+}
+extern "C" int rt_group_synchronize(RtGroup* g)
+{
+    if (!g) return fail(RT_E_INVALID, "rt_group_synchronize: null group");
+    for (RtCtx* c : g->lane) { const int rc = rt_synchronize(c); if (rc != RT_OK) return rc; }
+    return RT_OK;
+}
+// The lane-ordered sum of the lanes' accumulators, on the device: into `devicePtr` (float4[width*height], e.g. the tensor a
+// torch.distributed all_reduce then works on) or, when NULL, into the group's own buffer.  Queued on lane 0's stream behind every
+// lane's pending frames; rt_group_synchronize (or rt_group_read_accum) waits for it.
+extern "C" int rt_group_sum(RtGroup* g, void* devicePtr)
+{
+    if (!g) return fail(RT_E_INVALID, "rt_group_sum: null group");
+    RtCtx* c0 = g->lane[0];
+    HIPCHK(hipSetDevice(c0->cfg.device));
+    const int n = (int)g->lane.size();
+    for (int m = 1; m < n; m++) { HIPCHK(hipEventRecord(g->done[(size_t)m], g->lane[(size_t)m]->stream)); HIPCHK(hipStreamWaitEvent(c0->stream, g->done[(size_t)m], 0)); }
+    const float4* a[kMaxLanes];
+    for (int m = 0; m < kMaxLanes; m++) a[m] = g->lane[(size_t)std::min(m, n - 1)]->q.accum;
+    hipLaunchKernelGGL(k_sum_lanes, grid_for(c0->nPix), dim3(kBlock), 0, c0->stream, devicePtr ? (float4*)devicePtr : g->sum,
+                       a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], n, c0->firstPixel, c0->nPix);
+    HIPCHK(hipGetLastError());
+    // the lanes must not start overwriting their accumulators before the sum has read them
+    HIPCHK(hipEventRecord(g->done[0], c0->stream));
+    for (int m = 1; m < n; m++) HIPCHK(hipStreamWaitEvent(g->lane[(size_t)m]->stream, g->done[0], 0));
+    return RT_OK;
+}
+extern "C" int rt_group_read_accum(RtGroup* g, RtFloat4* out)
+{
+    if (!g || !out) return fail(RT_E_INVALID, "rt_group_read_accum: null argument");
+    int rc = rt_group_sum(g, nullptr); if (rc != RT_OK) return rc;
+    rc = rt_group_synchronize(g); if (rc != RT_OK) return rc;
+    const RtCtx* c0 = g->lane[0];
+    HIPCHK(hipMemcpy(out, g->sum, sizeof(float4) * (size_t)c0->cfg.width * c0->cfg.height, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+extern "C" int rt_group_focus(RtGroup* g, int32_t x, int32_t y, const RtCamera* cam, float* t) { return g ? rt_focus(g->lane[0], x, y, cam, t) : fail(RT_E_INVALID, "rt_group_focus: null group"); }
+// Renderer::PostProc + SaveFrame over the group's accumulator; `frames` is the group's frame count (rt_group_frames) unless > 0.
+extern "C" int rt_group_postproc(RtGroup* g, int32_t frames, float vignette, float gamma, float chromatic, RtFloat4* outF32, uint8_t* outRGBA8)
+{
+    if (!g) return fail(RT_E_INVALID, "rt_group_postproc: null group");
+    RtCtx* c0 = g->lane[0];
+    if (g->lane.size() == 1) return rt_postproc(c0, frames > 0 ? frames : (int32_t)std::max<uint64_t>(g->frames, 1), vignette, gamma, chromatic, outF32, outRGBA8);
+    int rc = rt_group_sum(g, nullptr); if (rc != RT_OK) return rc;
+    float4* own = c0->q.accum;
+    c0->q.accum = g->sum;                  // k_postproc reads the accumulator it is handed: the summed one
+    rc = rt_postproc(c0, frames > 0 ? frames : (int32_t)std::max<uint64_t>(g->frames, 1), vignette, gamma, chromatic, outF32, outRGBA8);
+    c0->q.accum = own;
+    return rc;
 }
 
 #ifdef RT355_TAIL_PROBE

@@ -817,8 +817,9 @@ RT_FORCEINLINE void trace_short_queue(const DevScene& sc, const DevQueues& q, in
     uint32_t rays = 0;
     TRay r; r.t = 0; r.prim = -1; r.u = r.v = 0; r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.rx = r.ry = r.rz = 0;
     int idx = waveId * 64 + lane;
-    if (!OCC && b0 == 0 && ((q.width | (q.nPix / q.width)) & 7) == 0) {
-        // primary rays: a wave takes an 8x8 pixel tile instead of a 64x1 strip (the queue of bounce 0 is the pixel grid)
+    if (!OCC && b0 == 0 && ((q.width | (q.nPix / q.width)) & 7) == 0 && n == q.nPix && (long long)gridDim.x * kBlock >= (long long)q.nPix) {
+        // primary rays: a wave takes an 8x8 pixel tile instead of a 64x1 strip (the queue of bounce 0 is the pixel grid - only when it IS
+        // the whole grid and the launch has a wave for every tile; an injected shorter queue or a smaller grid keeps the strip mapping)
         const int tilesX = q.width >> 3, ty = waveId / tilesX, tx = waveId - ty * tilesX;
         idx = ((ty << 3) + (lane >> 3)) * q.width + (tx << 3) + (lane & 7);
     }
@@ -1045,7 +1046,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist4(DevScene sc, DevQueue
 
     if (n <= nWaves * 64) {   // short queue: plain one-ray-per-lane loop
         int idx = waveId * 64 + lane;
-        if (!OCC && b0 == 0 && ((q.width | (q.nPix / q.width)) & 7) == 0) {   // primary rays: 8x8 pixel tile per wave
+        if (!OCC && b0 == 0 && ((q.width | (q.nPix / q.width)) & 7) == 0 && n == q.nPix && (long long)gridDim.x * kBlock >= (long long)q.nPix) {   // primary rays: 8x8 pixel tile per wave (see trace_short_queue)
             const int tilesX = q.width >> 3, ty = waveId / tilesX, tx = waveId - ty * tilesX;
             idx = ((ty << 3) + (lane >> 3)) * q.width + (tx << 3) + (lane & 7);
         }

@@ -29,13 +29,14 @@ def band_rows(height, rank, world):
 
 
 def seed_offset(shard, width, height, rank, world, lane=0, lanes=1):
-    """First index into the reference's host seed stream for this rank (and lane), and the number of seeds."""
+    """First index into the reference's host seed stream for this rank (and lane), and the number of seeds.  A context renders sample
+    stream `stream` (the stream-th slice of W*H seeds) restricted to its rows: samples plan - every (rank, lane) has a stream of its
+    own, rank * lanes + lane, and renders all rows; band plans - the ranks split the ROWS, and the lanes of a band are sample streams
+    0 .. lanes-1 of those rows (lane 0 alone is the frame's own seed slice, as the reference would render the band)."""
     if shard == "samples":
         return (rank * lanes + lane) * width * height, width * height
-    if lanes != 1:
-        raise ValueError("lanes partition samples; the band plan runs one context per rank")
     y0, y1 = band_rows(height, rank, world)
-    return y0 * width, (y1 - y0) * width
+    return lane * width * height + y0 * width, (y1 - y0) * width
 
 
 def plan(shard, width, height, rank, world, lane=0, lanes=1):
@@ -46,7 +47,7 @@ def plan(shard, width, height, rank, world, lane=0, lanes=1):
     else:
         raise ValueError(f"unknown shard mode {shard!r}")
     first, n = seed_offset(shard, width, height, rank, world, lane, lanes)
-    return dict(y0=y0, y1=y1, seed_first=first, seed_count=n)
+    return dict(y0=y0, y1=y1, seed_first=first, seed_count=n, stream=(rank * lanes + lane) if shard == "samples" else lane)
 
 
 def interleaved_bands(height, rank, world, band_rows=None):
@@ -60,10 +61,14 @@ def plans(shard, width, height, rank, world, lane=0, lanes=1, band_rows=None):
     """All contexts of this rank (and lane): one plan for "samples" / "bands", one per owned band for "ibands"."""
     if shard != "ibands":
         return [plan(shard, width, height, rank, world, lane, lanes)]
-    if lanes != 1:
-        raise ValueError("lanes partition samples; the band plans run one context per band")
-    return [dict(y0=y0, y1=y1, seed_first=y0 * width, seed_count=(y1 - y0) * width)
+    return [dict(y0=y0, y1=y1, seed_first=lane * width * height + y0 * width, seed_count=(y1 - y0) * width, stream=lane)
             for y0, y1 in interleaved_bands(height, rank, world, band_rows)]
+
+
+def rank_frames(total, rank, world):
+    """Strong scaling of a fixed render (`--total-steps`): how many of `total` 1-spp frames rank `rank` renders under the sample
+    plan (the first total % world ranks take one more)."""
+    return total // world + (1 if rank < total % world else 0)
 
 
 def lane_frames(frames, lanes):
@@ -113,6 +118,49 @@ class Lanes:
     def close(self):
         for d in self.devs:
             d.close()
+
+
+class Groups:
+    """The library-level lanes of one rank: one renderer.Group (rt_group_*: `lanes` sample streams behind one handle, one device copy
+    of the scene) per row band the rank owns - ONE group for the "samples" and "bands" plans, one per owned band for "ibands"."""
+
+    def __init__(self, groups):
+        self.groups = list(groups)
+
+    @property
+    def devs(self):
+        return [d for g in self.groups for d in g.devs]
+
+    def __len__(self):
+        return sum(len(g) for g in self.groups)
+
+    def render(self, cam, frames):
+        """`frames` frames of EVERY group (a group deals its frames to its lanes), queued in turns of one frame per lane so that all
+        contexts' kernels overlap on the GPU."""
+        left = [frames] * len(self.groups)
+        while any(left):
+            for k, g in enumerate(self.groups):
+                n = min(left[k], len(g))
+                if n:
+                    g.render(cam, n)
+                    left[k] -= n
+
+    def synchronize(self):
+        for g in self.groups:
+            g.synchronize()
+
+    def sum_into(self, tensor):
+        """Every group adds up its lanes (lane order) into its rows of `tensor`; the bands of a rank are disjoint."""
+        for g in self.groups:
+            g.sum_into(tensor)
+
+    def reset(self):
+        for g in self.groups:
+            g.reset()
+
+    def close(self):
+        for g in self.groups:
+            g.close()
 
 
 def init_process_group(backend=None, set_device=True):

@@ -79,6 +79,15 @@ int rth_build_bvh4(RthScene* s) { GUARD(s->scene.BuildBVH4()) }
 int rth_bvh4_from_nodes(const RtBVHNode2* nodes, int n, RtBVHNode4* out)
 {
     if (!nodes || !out || n <= 0) { g_herr = "rth_bvh4_from_nodes: bad argument"; return -1; }
+    {   // Convert / Collapse index children unchecked and recurse: refuse child ids out of range and nodes reachable twice (a cycle)
+        std::vector<uint32_t> st{ 0u };
+        size_t visited = 0;
+        while (!st.empty()) {
+            const uint32_t i = st.back(); st.pop_back();
+            if (i >= (uint32_t)n || ++visited > (size_t)n) { g_herr = "rth_bvh4_from_nodes: child index out of range or a node reachable twice"; return -1; }
+            if (nodes[i].count == 0) { st.push_back(nodes[i].first); st.push_back(nodes[i].first + 1); }
+        }
+    }
     try {
         std::vector<RtPrimitive> prims; std::vector<RtBVHInstance> blas(1);
         memset(&blas[0], 0, sizeof blas[0]);
@@ -184,6 +193,8 @@ extern "C" int rth_save_png(const char* file, int w, int h, const RtFloat4* data
 extern "C" int rth_renderer_camera_move(RthRenderer* r, int camdir) { GUARD(r->r->camera.Move(camdir, 0.0f)) }
 extern "C" int rth_renderer_camera_mouse(RthRenderer* r, float dx, float dy) { GUARD(r->r->camera.MouseMove(dx, dy)) }
 extern "C" int rth_renderer_camera_zoom(RthRenderer* r, float offset) { GUARD(r->r->camera.Zoom(offset)) }
+// sample streams behind the Renderer (before Init): Tick() then renders `lanes` frames whose kernels overlap (include/rt355.h, rt_group_*)
+extern "C" int rth_renderer_set_lanes(RthRenderer* r, int lanes) { if (!r || lanes < 1 || lanes > 8) { g_herr = "rth_renderer_set_lanes: lanes must be 1..8"; return -1; } r->r->lanes = lanes; return 0; }
 extern "C" int rth_renderer_frames(RthRenderer* r) { return r && r->r->settings ? r->r->settings->frames : -1; }
 extern "C" int rth_renderer_save_frame(RthRenderer* r, const char* file) { GUARD(r->r->SaveFrame(file)) }
 

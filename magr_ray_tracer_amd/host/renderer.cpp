@@ -22,7 +22,7 @@ Renderer::Renderer(int w, int h, int dev, int band0, int band1)
 }
 Renderer::~Renderer()
 {
-    if (ctx) rt_destroy(ctx);
+    if (group) rt_group_destroy(group);
     delete tlas;
     delete settings;
 }
@@ -49,17 +49,20 @@ void Renderer::Init() // renderer.cpp:6-21 (+ InitBuffers :142-209, InitWavefron
     cfg.shading = imgui.shading; cfg.sampling = imgui.sampling; cfg.accel = imgui.bvh;
     cfg.russian_roulette = imgui.use_russian_roulette; cfg.filter_fireflies = imgui.filter_fireflies;
     cfg.device = device;
-    if (ctx) { rt_destroy(ctx); ctx = nullptr; }
-    check(rt_create(&cfg, &ctx), "rt_create");
+    // `lanes` sample streams behind this one Renderer (rt_group_*, include/rt355.h): 1 = the reference's single in-order queue, bit for
+    // bit; more keep the GPU full (the lanes' frames overlap) and turn one Tick() into `lanes` frames of the same accumulation
+    if (group) { rt_group_destroy(group); group = nullptr; ctx = nullptr; }
+    check(rt_group_create(&cfg, lanes < 1 ? 1 : lanes, &group), "rt_group_create");
+    ctx = rt_group_lane(group, 0);
     const bool q = imgui.bvh == RT_ACCEL_BVH4;
-    check(rt_upload_scene(ctx, scene.primitives.data(), (int)scene.primitives.size(), scene.materials.data(), (int)scene.materials.size(),
+    check(rt_group_upload_scene(group, scene.primitives.data(), (int)scene.primitives.size(), scene.materials.data(), (int)scene.materials.size(),
                           scene.textures.data(), (int)scene.textures.size(), scene.lights.data(), (int)scene.lights.size(),
                           q ? (const void*)scene.bvh4->Nodes().data() : (const void*)scene.bvh2->bvhNodes.data(),
                           q ? (int)scene.bvh4->Nodes().size() : (int)scene.bvh2->bvhNodes.size(),
                           scene.bvh2->primIdx.data(), (int)scene.bvh2->primIdx.size(),
                           tlas->tlasNodes.data(), (int)tlas->tlasNodes.size(), scene.blasNodes.data(), (int)scene.blasNodes.size()),
-          "rt_upload_scene");
-    check(rt_seed_default(ctx), "rt_seed_default");
+          "rt_group_upload_scene");
+    check(rt_group_seed(group, 0), "rt_group_seed");   // lane m: the (m * PIXELS + i + 1)-th outputs of the host stream (renderer.cpp:195-196)
     camera.UpdateCamVec();
     FocusCamera(width / 2, height / 2);
 }
@@ -68,17 +71,17 @@ void Renderer::Tick(float) // renderer.cpp:26-63
 {
     camera.UpdateCamVec();
     if (camera.moved || imgui.reset_every_frame) {
-        check(rt_reset(ctx), "rt_reset");
+        check(rt_group_reset(group), "rt_group_reset");
         camera.moved = false;
         settings->frames = 1;
     }
     if (settings->renderBVH) settings->frames = 1;
     RayTrace();
-    settings->frames++;
+    settings->frames += rt_group_lanes(group);   // renderer.cpp:53 `frames++`, once per frame a lane has added to the accumulation
 }
-void Renderer::RayTrace() // renderer.cpp:64-94
+void Renderer::RayTrace() // renderer.cpp:64-94, once per lane: the lanes' launches are queued interleaved and overlap on the GPU
 {
-    check(rt_render(ctx, &camera.cam, settings, 1), "rt_render");
+    check(rt_group_render(group, &camera.cam, settings, rt_group_lanes(group)), "rt_group_render");
 }
 void Renderer::FocusCamera(int x, int y) // renderer.cpp:289-301
 {
@@ -87,13 +90,13 @@ void Renderer::FocusCamera(int x, int y) // renderer.cpp:289-301
     settings->focalLength = t;
     if (t != RT_REALLYFAR) camera.cam.focalLength = t;
 }
-void Renderer::ReadAccum(RtFloat4* out) { check(rt_read_accum(ctx, out), "rt_read_accum"); }
+void Renderer::ReadAccum(RtFloat4* out) { check(rt_group_read_accum(group, out), "rt_group_read_accum"); }
 void Renderer::SaveFrame(const char* file) // renderer.cpp:303-308 after PostProc (:95-124)
 {
     std::vector<RtFloat4> img((size_t)width * height);
     // Tick() has already advanced settings->frames past the frame whose image is shown (renderer.cpp:49-53)
     int shown = settings->frames > 1 ? settings->frames - 1 : 1;
-    check(rt_postproc(ctx, shown, vignet_strength, gamma_strength, chromatic_strength, img.data(), nullptr), "rt_postproc");
+    check(rt_group_postproc(group, shown, vignet_strength, gamma_strength, chromatic_strength, img.data(), nullptr), "rt_group_postproc");
     SavePNG(file, width, height, img.data());
 }
 void Renderer::ComputeEnergy() // renderer.cpp:126-140

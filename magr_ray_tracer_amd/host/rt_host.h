@@ -15,6 +15,7 @@
 #include "../../include/rt355_types.h"
 
 struct RtCtx;
+struct RtGroup;
 
 namespace rt355 {
 
@@ -208,7 +209,9 @@ public:
     TLAS*          tlas = nullptr;
     RenderOptions  imgui;
     float          energy_total = 0;
-    RtCtx*         ctx = nullptr;
+    RtGroup*       group = nullptr;    // the lanes behind this Renderer (include/rt355.h, rt_group_*)
+    RtCtx*         ctx = nullptr;      // lane 0 (focus pick, counters, stage-level debugging)
+    int            lanes = 1;          // set before Init(): sample streams whose frames overlap on the GPU; Tick() = `lanes` frames
     int width, height, device, y0, y1;
 };
 

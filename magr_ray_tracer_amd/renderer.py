@@ -37,14 +37,28 @@ class Device:
         self._h = h
         self._keep = None
 
+    @classmethod
+    def borrowed(cls, handle, cfg):
+        """A Device view of a context somebody else owns (a lane of a Group): same methods, close() does not destroy it."""
+        d = cls.__new__(cls)
+        d._lib = _lib.device_lib()
+        d.cfg = cfg
+        d.width, d.height = int(cfg["width"]), int(cfg["height"])
+        d.y0, d.y1 = int(cfg["y0"]), int(cfg["y1"])
+        d.npix = (d.y1 - d.y0) * d.width
+        d.first_pixel = d.y0 * d.width
+        d.accel = int(cfg["accel"])
+        d._h, d._keep, d._owned = C.c_void_p(handle), None, False
+        return d
+
     def _chk(self, rc):
         if rc != 0:
             raise RtError(self._lib.rt_last_error().decode())
 
     def close(self):
-        if self._h:
+        if self._h and getattr(self, "_owned", True):
             self._lib.rt_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:
@@ -213,6 +227,112 @@ class Device:
         return out
 
 
+class Group:
+    """One accumulation rendered as `lanes` interleaved sample streams behind one handle (rt_group_*, include/rt355.h): own context,
+    stream, queues and seed slice per lane, ONE device copy of the scene, accumulator = sum of the lanes in lane order."""
+
+    def __init__(self, width, height, lanes=4, y0=0, y1=None, shading=_lib.SHADING_NEE, sampling=_lib.SAMPLING_COSINE,
+                 accel=_lib.ACCEL_BVH2, russian_roulette=True, filter_fireflies=True, max_bounces=_lib.MAX_BOUNCES,
+                 device=0, profile=False, extend_variant=0, shade_blocks_per_cu=0, persist_blocks_per_cu=0):
+        self._lib = _lib.device_lib()
+        cfg = np.zeros((), dtype=_lib.Config)
+        cfg["width"], cfg["height"], cfg["y0"], cfg["y1"] = width, height, y0, height if y1 is None else y1
+        cfg["max_bounces"], cfg["shading"], cfg["sampling"], cfg["accel"] = max_bounces, shading, sampling, accel
+        cfg["russian_roulette"], cfg["filter_fireflies"] = int(russian_roulette), int(filter_fireflies)
+        cfg["device"], cfg["profile"], cfg["extend_variant"] = device, (2 if profile is True else int(profile)), extend_variant
+        cfg["shade_blocks_per_cu"], cfg["persist_blocks_per_cu"] = shade_blocks_per_cu, persist_blocks_per_cu
+        self.cfg, self.width, self.height, self.accel = cfg, width, height, accel
+        self.y0, self.y1 = int(cfg["y0"]), int(cfg["y1"])
+        h = C.c_void_p()
+        self._h = None
+        self._chk(self._lib.rt_group_create(cfg.ctypes.data_as(C.c_void_p), int(lanes), C.byref(h)))
+        self._h = h
+        self.devs = [Device.borrowed(self._lib.rt_group_lane(self._h, m), cfg) for m in range(lanes)]
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RtError(self._lib.rt_last_error().decode())
+
+    def __len__(self):
+        return len(self.devs)
+
+    def concurrency(self):
+        """How many of the lanes' HIP streams were measured to run side by side when the group was created."""
+        return int(self._lib.rt_group_concurrency(self._h))
+
+    def frames(self):
+        return int(self._lib.rt_group_frames(self._h))
+
+    def upload(self, sa):
+        nodes = sa.nodes(self.accel)
+        P = _lib.ptr
+        self._chk(self._lib.rt_group_upload_scene(
+            self._h, P(sa.prims), len(sa.prims), P(sa.mats), len(sa.mats), P(sa.tex) if len(sa.tex) else None, len(sa.tex),
+            P(sa.lights) if len(sa.lights) else None, len(sa.lights), P(nodes), len(nodes), P(sa.primIdx), len(sa.primIdx),
+            P(sa.tlas), len(sa.tlas), P(sa.blas), len(sa.blas)))
+
+    def share_scene(self, other):
+        """Render the scene another Group on the same GPU holds, from its device copy."""
+        self._chk(self._lib.rt_group_share_scene(self._h, other._h))
+
+    def seed(self, first_stream=0):
+        self._chk(self._lib.rt_group_seed(self._h, int(first_stream)))
+
+    def reset(self):
+        self._chk(self._lib.rt_group_reset(self._h))
+
+    def render(self, cam, frames=1, antiAliasing=1):
+        s = np.zeros((), dtype=_lib.Settings)
+        s["antiAliasing"] = antiAliasing
+        c = np.ascontiguousarray(cam)
+        self._chk(self._lib.rt_group_render(self._h, c.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), int(frames)))
+
+    def synchronize(self):
+        self._chk(self._lib.rt_group_synchronize(self._h))
+
+    def sum_into(self, tensor):
+        """Lane-ordered sum of the lanes' accumulators into a torch CUDA tensor (H, W, 4) float32, queued behind the pending frames."""
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.numel() == self.width * self.height * 4
+        self._chk(self._lib.rt_group_sum(self._h, C.c_void_p(tensor.data_ptr())))
+
+    def focus(self, x, y, cam):
+        t = C.c_float(0)
+        c = np.ascontiguousarray(cam)
+        self._chk(self._lib.rt_group_focus(self._h, int(x), int(y), c.ctypes.data_as(C.c_void_p), C.byref(t)))
+        return np.float32(t.value)
+
+    def read_accum(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        self._chk(self._lib.rt_group_read_accum(self._h, _lib.ptr(out)))
+        return out
+
+    def postproc(self, frames=0, vignette=0.0, gamma=0.9, chromatic=0.0):
+        f = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        b = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        self._chk(self._lib.rt_group_postproc(self._h, int(frames), float(vignette), float(gamma), float(chromatic), _lib.ptr(f), _lib.ptr(b)))
+        return f, b
+
+    def counters(self):
+        """Work totals over the lanes."""
+        tot = {}
+        for d in self.devs:
+            for k, v in d.counters().items():
+                tot[k] = tot.get(k, 0) + v
+        return tot
+
+    def close(self):
+        if self._h:
+            self.devs = []
+            self._lib.rt_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Renderer:
     """The C++ Renderer mirror (host/renderer.cpp): Init(), Tick(), accumulator read-back, energy."""
 
@@ -231,6 +351,10 @@ class Renderer:
 
     def SetCamera(self, origin, forward, fov=110.0, aperture=0.1):
         self._chk(self._lib.rth_renderer_set_camera(self._h, _lib.fvec(origin), _lib.fvec(forward), float(fov), float(aperture)))
+
+    def SetLanes(self, lanes):
+        """Before Init(): render the accumulation as `lanes` interleaved sample streams; a Tick() is then `lanes` frames."""
+        self._chk(self._lib.rth_renderer_set_lanes(self._h, int(lanes)))
 
     def Init(self):
         self._chk(self._lib.rth_renderer_init(self._h))

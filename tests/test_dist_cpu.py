@@ -104,8 +104,13 @@ def test_lanes_are_virtual_ranks_of_the_sample_plan():
             seen.append(p["seed_first"])
     assert seen == [v * P for v in range(world * lanes)]
     assert rdist.plan("samples", W, H, 2, world) == rdist.plan("samples", W, H, 2, world, 0, 1)
-    with pytest.raises(ValueError):
-        rdist.plan("bands", W, H, 0, world, 0, 2)
+    # band plans: the ranks split the rows, the lanes of a band are sample streams 0 .. lanes-1 of THOSE rows (lane 0 = the frame's own slice)
+    for r in range(world):
+        y0, y1 = rdist.band_rows(H, r, world)
+        for m in range(lanes):
+            p = rdist.plan("bands", W, H, r, world, m, lanes)
+            assert (p["y0"], p["y1"], p["seed_first"], p["seed_count"], p["stream"]) == (y0, y1, m * P + y0 * W, (y1 - y0) * W, m)
+    assert [rdist.rank_frames(1024, r, 8) for r in range(8)] == [128] * 8 and sum(rdist.rank_frames(10, r, 4) for r in range(4)) == 10
     for frames in (0, 1, 5, 256):
         for n in (1, 2, 3):
             parts = rdist.lane_frames(frames, n)

@@ -866,7 +866,11 @@ def test_bench_starts_its_own_ranks_two_on_one_gpu(tmp_path):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == steps and line["repeats"] == 1
     assert len(line["rank_s"]["render"]) == 2 and len(line["rank_s"]["all_reduce"]) == 2 and line["value"] > 0
-    assert line["roofline"]["kernel"].startswith("extend = k_trace_persist<false>") and line["roofline"]["gather"]["frac"] > 0
+    roof = line["roofline"]
+    assert roof["kernel"].startswith("extend = k_trace_persist<false>") and roof["algorithmic"]["gbs"] > 0 and roof["avg_launch_ms"] > 0
+    # the kernel's own launch time comes from ONE context with the GPU to itself: its seven extend launches fit inside that context's frame
+    assert 7 * roof["avg_launch_ms"] <= 1e3 * Wd * Hd * 2 / (line["value_single_context"] * 1e6) * 1.02
+    assert all(0 < v["frac"] <= 1 for v in roof["levels"].values())     # (empty unless a committed PMC measurement matches this frame size)
     got = np.load(dump)
     s, view = scenes.sponza_class(0.2)
     sa = s.arrays(bvh4=False)
@@ -1210,8 +1214,10 @@ def test_bench_default_path_four_lanes_one_scene_copy_vs_oracle(tmp_path):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["lanes"] == 4 and line["config"]["contexts"] == 4 and line["steps"] == steps
     assert line["metric"].startswith("Mrays/sec") and line["dtype"] == "f32" and line["vs_baseline"] is None and line["value"] > 0
+    # the four lanes' streams really run side by side although nothing in this environment asked for hardware queues: the library does
+    assert line["config"]["streams_concurrent"] == 4
     roof = line["roofline"]
-    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["achieved"] > 0 and 0 < roof["gather"]["job_frac"] < 1.5
+    assert roof["job"]["lanes"] == 4 and roof["job"]["algorithmic_gbs"] > 0 and roof["job"]["ms_per_step"] > 0
     got = np.load(dump)
     s, view = scenes.sponza_class(0.2)
     sa = s.arrays(bvh4=False)
