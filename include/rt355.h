@@ -50,7 +50,8 @@ typedef struct RtConfig {
     int32_t device;             /* HIP device ordinal                                         */
     int32_t extend_variant;     /* traversal kernels: 0 = best available (derived node/triangle layout + persistent
                                  * wavefronts when the TLAS has one BLAS), 1 = traverse the reference arrays as uploaded,
-                                 * one ray per lane, 2 = derived layout, one ray per lane                            */
+                                 * one ray per lane, 2 = derived layout, one ray per lane, 4 = as 0 but multi-BLAS scenes keep the
+                                 * one-ray-per-lane nested TLAS loops instead of k_trace_persist_tlas (A/B runs)      */
     int32_t profile;            /* HIP-event brackets on the context's stream: 0 none, 1 extend launches only
                                  * (what the roofline needs; ~1 % overhead), 2 every stage launch (~3.5 %)        */
     int32_t shade_blocks_per_cu;/* k_shade workgroups per CU: 0 = what the CUs hold (2, best for one context with the GPU to itself);
@@ -69,6 +70,10 @@ typedef struct RtCounters {
     uint64_t primary_rays;       /* pixels generated                     */
     uint64_t shadow_rays;        /* shadow rays appended by shade        */
     uint64_t frames;
+    /* how often the persistent event loops issued their two code paths (wave level): node_visits / (64 * node_issues) is the share of
+     * the lanes that had a box pair to test when the node path ran, prim_tests / (64 * leaf_issues) the same for the triangle path
+     * (0 for launches that ran one ray per lane) */
+    uint64_t extend_node_issues, extend_leaf_issues, connect_node_issues, connect_leaf_issues;
 } RtCounters;
 
 /* Accumulated stage times in milliseconds (HIP events on the context's stream) and
@@ -81,7 +86,9 @@ typedef struct RtStageTimes {
 /* Which kernels a context runs for the uploaded scene (chosen at rt_upload_scene; bench.py names the roofline's kernel from it). */
 typedef struct RtKernelInfo {
     int32_t layout;               /* 0 = the reference arrays as uploaded, 1 = derived pair / quad / triangle records */
-    int32_t persist, persist4;    /* persistent-wavefront traversal over the BVH2 / BVH4 (one BLAS)                  */
+    int32_t persist, persist4;    /* persistent-wavefront traversal over the BVH2 (1: one BLAS, 2: through a multi-BLAS
+                                   * TLAS, k_trace_persist_tlas, 3: the same with the deep end of the traversal stacks
+                                   * spilled to global memory) / over the BVH4 (one BLAS)                             */
     int32_t stack_entries;        /* LDS traversal stack entries per lane                                             */
     int32_t persist_grid, persist_grid_connect, shade_grid;   /* workgroups of the persistent launches                */
     int32_t n_blas;

@@ -36,7 +36,7 @@ ShadowRecord = np.dtype([("o", "<f4", 3), ("tmax", "<f4"), ("l", "<f4", 3), ("pi
 Counters = np.dtype([(n, "<u8") for n in (
     "extend_rays", "extend_tlas_visits", "extend_inst_visits", "extend_node_visits", "extend_prim_tests",
     "connect_rays", "connect_tlas_visits", "connect_inst_visits", "connect_node_visits", "connect_prim_tests",
-    "primary_rays", "shadow_rays", "frames")])
+    "primary_rays", "shadow_rays", "frames", "extend_node_issues", "extend_leaf_issues", "connect_node_issues", "connect_leaf_issues")])
 StageTimes = np.dtype([(n, "<f8") for n in ("generate_ms", "extend_ms", "shade_ms", "compact_ms", "connect_ms", "accumulate_ms")] +
                       [(n, "<i8") for n in ("generate_launches", "extend_launches", "shade_launches", "compact_launches",
                                             "connect_launches", "accumulate_launches")])
@@ -86,20 +86,37 @@ class NativeLibraryMissing(RuntimeError):
     pass
 
 
-def _load(name):
+def _load(name, local=False):
     path = os.path.join(_PKG, name)
     if not os.path.exists(path):
         raise NativeLibraryMissing(
             f"{path} is missing: build it with `python -m magr_ray_tracer_amd.build` (hipcc, gfx950). "
             "The hot path has no Python/CPU fallback.")
-    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return C.CDLL(path, mode=C.RTLD_LOCAL if local else C.RTLD_GLOBAL)   # a variant build exports the same symbols: keep them out of the global namespace
 
 
-def device_lib():
-    """librt355.so with argtypes set. Raises NativeLibraryMissing if it was not built."""
+_variants = {}
+
+
+def device_lib(variant=None):
+    """librt355.so with argtypes set. Raises NativeLibraryMissing if it was not built.  variant="refb": librt355_refb.so, the build with
+    the reference's OpenCL builtin sequences (-DRT355_REF_BUILTINS; tests against the reference's kernels only)."""
     global _dev
+    if variant:
+        if variant not in _variants:
+            keep, _dev = _dev, None
+            try:
+                _variants[variant] = _bind_device(_load(f"librt355_{variant}.so", local=True))
+            finally:
+                _dev = keep
+        return _variants[variant]
     if _dev is None:
-        lib = _load("librt355.so")
+        _dev = _bind_device(_load("librt355.so"))
+    return _dev
+
+
+def _bind_device(lib):
+    if True:
         vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
         lib.rt_last_error.restype = C.c_char_p
         lib.rt_create.argtypes = [vp, C.POINTER(vp)]
@@ -156,8 +173,7 @@ def device_lib():
         lib.rt_group_read_accum.argtypes = [vp, vp]
         lib.rt_group_focus.argtypes = [vp, i32, i32, vp, C.POINTER(C.c_float)]
         lib.rt_group_postproc.argtypes = [vp, i32, C.c_float, C.c_float, C.c_float, vp, vp]
-        _dev = lib
-    return _dev
+    return lib
 
 
 def host_lib():

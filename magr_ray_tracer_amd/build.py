@@ -4,6 +4,7 @@
 
 Outputs (git-ignored, shipped to the GPU box by gpurun):
     magr_ray_tracer_amd/librt355.so       device path: HIP kernels + C-ABI (include/rt355.h)
+    magr_ray_tracer_amd/librt355_refb.so  the same with the reference's OpenCL builtin sequences (tests only, -DRT355_REF_BUILTINS)
     magr_ray_tracer_amd/librt355_host.so  host side: Scene / BVH2 / BVH4 / TLAS / Renderer mirror
     oracle/liboracle.so                   CPU restatement (test infrastructure only)
 """
@@ -42,6 +43,19 @@ def build_device(force=False):
     out = os.path.join(PKG, "librt355.so")
     if force or _stale(out, deps):
         _run([HIPCC] + DEVICE_FLAGS + [src, "-o", out])
+    return out
+
+
+def build_device_refb(force=False):
+    """librt355_refb.so: the same library with -DRT355_REF_BUILTINS (normalize / length / exp / sin / cos / acospi / atan2pi as ROCm's
+    OpenCL library evaluates them for the reference's kernels, rt355_kernels.h).  Test infrastructure for tests/test_gpu_reference.py
+    (uncurated whole-frame comparison with the reference's kernels); the shipped library is librt355.so."""
+    src = os.path.join(PKG, "csrc", "rt355.hip")
+    deps = [src, os.path.join(PKG, "csrc", "rt355_kernels.h"), os.path.join(ROOT, "include", "rt355.h"),
+            os.path.join(ROOT, "include", "rt355_types.h")]
+    out = os.path.join(PKG, "librt355_refb.so")
+    if force or _stale(out, deps):
+        _run([HIPCC] + DEVICE_FLAGS + ["-DRT355_REF_BUILTINS", src, "-o", out])
     return out
 
 
@@ -84,6 +98,7 @@ def build_ref(force=False):
 
 def build_all(force=False):
     build_device(force)
+    build_device_refb(force)
     build_host(force)
     build_examples(force)
     build_oracle(force)

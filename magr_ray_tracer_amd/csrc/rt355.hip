@@ -20,6 +20,7 @@ using namespace rt355dev;
 
 // workgroups of 256 threads the hardware admits per CU whatever the occupancy query says: any kernel / kernels with <= 96 SGPRs
 static constexpr int kAdmitAnySgpr = 6, kAdmit96Sgpr = 7;
+static constexpr int kSpillCap = 20, kFitSeven = 22;   // LDS stack entries per lane: 22 x 1 KB per workgroup is the most with which seven workgroups share a CU's 160 KB; a spilling kernel keeps 20
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...)
 {
@@ -61,11 +62,16 @@ struct RtCtx {
     int layout = 0;   // 0 = traverse the reference arrays as uploaded, 1 = derived pair/triangle-record layout
     bool persist = false;   // persistent-wavefront traversal (layout 1, single BLAS)
     bool persist4 = false;  // ... over the BVH4
+    bool persistTlas = false;   // ... through a multi-BLAS TLAS (BVH2, layout 1): k_trace_persist_tlas
+    bool spillStack = false;    // ... with the deep end of the traversal stacks in global memory (trees deeper than the LDS share of 7 workgroups per CU)
+    uint32_t* dSpill = nullptr; size_t spillWords = 0;
+    int spillCap = kSpillCap;   // LDS entries per lane of a spilling kernel (RT355_SPILL_CAP: tests force the spill path with a tiny cap, >= 6)
+    int nInterior = 0;          // records of the dense pair table (their ids must fit the 29-bit field of the tagged stack entries)
     bool cursorUsed[2 * (RT_MAX_BOUNCES + 2)] = {};   // work-queue heads consumed since the last k_begin_frame
     bool shadeRun[RT_MAX_BOUNCES + 1] = {};           // shade(b) launched since the last k_begin_frame
     bool generated = false;                           // generate launched since the last k_begin_frame
     int stackEntries = RT_BVH2_STACK, persistGrid = 0, persistGridConnect = 0;
-    PersistTune tune{ 112, 24, 6, 8, 0 }, tuneConnect{ 128, 32, 6, 16, 0 }, tune4{ 64, 20, 6, 8, 0 };   // extend (BVH2), connect, extend (BVH4): measured optima (tools/tune_extend.sh, tune_connect.sh, tune_persist.sh)
+    PersistTune tune{ 112, 24, 6, 8, 0, 0 }, tuneConnect{ 128, 32, 6, 16, 0, 0 }, tune4{ 64, 20, 6, 8, 0, 0 };   // extend (BVH2), connect, extend (BVH4): measured optima (tools/tune_extend.sh, tune_connect.sh, tune_persist.sh)
     float4* dPostF = nullptr; uchar4* dPostB = nullptr;   // post-processing outputs (lazy)
     int32_t* dSteps = nullptr;   // per-ray `steps` buffer, only bound while rt_debug_enable_steps is on
     int shadeTile = kTile;  // k_shade tile = workgroup size: kTile (512), or 256 for contexts that share the GPU (RtConfig.shade_blocks_per_cu > 0)
@@ -79,7 +85,7 @@ extern "C" int rt_kernel_info(RtCtx* ctx, RtKernelInfo* out)
 {
     if (!ctx || !out) return fail(RT_E_INVALID, "rt_kernel_info: null argument");
     if (!ctx->sceneLoaded) return fail(RT_E_INVALID, "rt_kernel_info: no scene uploaded");
-    *out = RtKernelInfo{ ctx->layout, ctx->persist ? 1 : 0, ctx->persist4 ? 1 : 0, ctx->stackEntries, ctx->persistGrid, ctx->persistGridConnect,
+    *out = RtKernelInfo{ ctx->layout, ctx->persist ? 1 : (ctx->persistTlas ? (ctx->spillStack ? 3 : 2) : 0), ctx->persist4 ? 1 : 0, ctx->spillStack ? ctx->spillCap : ctx->stackEntries, ctx->persistGrid, ctx->persistGridConnect,
                          ctx->shadeGrid, ctx->sc.nBlas };
     return RT_OK;
 }
@@ -99,6 +105,10 @@ static void free_bag(std::vector<void*>& bag) { for (void* p : bag) (void)hipFre
 // LDS traversal stack: one column per lane; sized at upload to what this scene's trees can need
 // (never more than the reference kernels' 32 / 64 entries).
 static size_t stack_bytes(const RtCtx* c) { return (size_t)c->stackEntries * kBlock * sizeof(uint32_t); }
+// k_trace_persist_tlas keeps its pending TLAS siblings (<= one per level) on the same column; with spillStack only the first kSpillCap
+// entries of a column live in LDS
+static int tlas_stack_entries(const RtCtx* c) { return c->stackEntries + c->tlasDepth + 1; }
+static size_t tlas_stack_bytes(const RtCtx* c) { return (size_t)(c->spillStack ? c->spillCap : tlas_stack_entries(c)) * kBlock * sizeof(uint32_t); }
 
 // ---- profiling brackets --------------------------------------------------------------
 // Stage timing: a fixed ring of HIP event pairs on the context's stream.  Recording never forces a device sync: when the ring
@@ -224,7 +234,7 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     QA(seeds, n); QA(accum, (size_t)c.width * c.height);
     if (rc == RT_OK) rc = dalloc(bag, &ctx->dSteps, n);
     q.steps = nullptr;
-    QA(ctrExtend, (size_t)ctx->gridMax * 5); QA(ctrConnect, (size_t)ctx->gridMax * 5);
+    QA(ctrExtend, (size_t)ctx->gridMax * kCtrCols); QA(ctrConnect, (size_t)ctx->gridMax * kCtrCols);
 #undef QA
     if (rc == RT_OK) rc = dalloc(bag, &ctx->dFocus, 1);
     if (rc != RT_OK) return rc;
@@ -235,8 +245,8 @@ extern "C" int rt_create(const RtConfig* cfg, RtCtx** out)
     (void)hipMemsetAsync(q.cursor, 0, sizeof(int32_t) * kCursorWords, ctx->stream);
     (void)hipMemsetAsync(q.shadeTicket, 0, sizeof(int32_t) * (size_t)(RT_MAX_BOUNCES + 1) * kTicketClasses * kTicketStride, ctx->stream);
     (void)hipMemsetAsync(q.fault, 0, sizeof(int32_t), ctx->stream);
-    (void)hipMemsetAsync(q.ctrExtend, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
-    (void)hipMemsetAsync(q.ctrConnect, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5, ctx->stream);
+    (void)hipMemsetAsync(q.ctrExtend, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * kCtrCols, ctx->stream);
+    (void)hipMemsetAsync(q.ctrConnect, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * kCtrCols, ctx->stream);
     (void)hipMemsetAsync(q.seeds, 0, sizeof(uint32_t) * n, ctx->stream);
     for (int k = 0; k < 2; k++) {
         (void)hipMemsetAsync(q.tile[k], 0, sizeof(unsigned long long) * (nTiles + 2), ctx->stream);
@@ -257,6 +267,7 @@ static void ctx_free(RtCtx* ctx)   // every owned resource; safe on a partially 
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->scene.reset(); free_bag(ctx->queueAllocs);
     if (ctx->dRayIO) (void)hipFree(ctx->dRayIO);
+    if (ctx->dSpill) (void)hipFree(ctx->dSpill);
     if (ctx->dPostF) (void)hipFree(ctx->dPostF);
     if (ctx->dPostB) (void)hipFree(ctx->dPostB);
     for (auto& e : ctx->evPool) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
@@ -383,7 +394,7 @@ static int validate_scene(int accel, const RtPrimitive* prims, int32_t nPrims, c
         for (int32_t i = 0; i < nNodes; i++) for (int k = 0; k < 4; k++) if (n4[i].first[k] != RT_INVALID && n4[i].count[k] > 0 &&
             (int64_t)n4[i].first[k] + n4[i].count[k] > (int64_t)nIdx) return fail(RT_E_INVALID, "bvh4 node %d: leaf range exceeds primIdx", i);
     }
-    if (stackEntriesOut) *stackEntriesOut = std::min(stackCap, std::max(stackNeed + 1, 6)); // >= 6: flush_counters reuses 20 words of it
+    if (stackEntriesOut) *stackEntriesOut = std::min(stackCap, std::max(stackNeed + 1, 6)); // >= 6: flush_counters reuses 28 words of it
     if (texPadOut) *texPadOut = texPad;
     if (tlasDepthOut) *tlasDepthOut = tlasDepth;
     return RT_OK;
@@ -403,7 +414,7 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
                                const RtTLASNode* tlas, int32_t nTlas, const RtBVHInstance* blas, int32_t nBlas)
 {
     if (!ctx) return fail(RT_E_INVALID, "rt_upload_scene: null context");
-    int stackEntries = RT_BVH2_STACK, tlasDepth = 0; int64_t texPad = 2;
+    int stackEntries = RT_BVH2_STACK, tlasDepth = 0, nInterior = 0; int64_t texPad = 2;
     {   // nothing of the context changes until the arrays have passed (a failed upload leaves the bound scene usable)
         const int vrc = validate_scene(ctx->cfg.accel, prims, nPrims, mats, nMats, textures, nTexels, lights, nLights, bvhNodes, nNodes, primIdx, nIdx,
                                        tlas, nTlas, blas, nBlas, &stackEntries, &texPad, &tlasDepth);
@@ -512,7 +523,7 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
             rc = upload(ctx, &sc.pairs, pairs.data(), pairs.size());
             if (rc == RT_OK) rc = upload(ctx, &sc.triRecs, recs.data(), recs.size());
             if (rc == RT_OK) rc = upload(ctx, &sc.rootEntry, roots.data(), roots.size());
-            if (rc == RT_OK) ctx->layout = 1;
+            if (rc == RT_OK) { ctx->layout = 1; nInterior = (int)order.size(); }
         }
     }
     if (rc == RT_OK && ctx->cfg.accel == RT_ACCEL_BVH4 && ctx->cfg.extend_variant != 1 && nIdx < (1 << 24)) {
@@ -599,12 +610,20 @@ extern "C" int rt_upload_scene(RtCtx* ctx, const RtPrimitive* prims, int32_t nPr
         rc = upload(ctx, &sc.tlasPairs, tp.data(), tp.size());
         if (rc == RT_OK) rc = upload(ctx, &sc.instRecs, ir.data(), ir.size());
         sc.tlasRoot = enc(0);
+        // the same records with the children in the tagged encoding of k_trace_persist_tlas (TLAS interior / instance ids on the BLAS stack)
+        auto encP = [&](uint32_t n) { return tlas[n].leftRight == 0 ? (kTagInst | tlas[n].BLASidx) : (kTagTlas | n); };
+        for (int32_t i = 0; i < nTlas; i++) {
+            const uint32_t lr = tlas[i].leftRight;
+            if (lr != 0) tp[(size_t)i * 4 + 3] = make_float4(f2u(encP(lr & 0xffffu)), f2u(encP(lr >> 16)), 0, 0);
+        }
+        if (rc == RT_OK) rc = upload(ctx, &sc.tlasPairsP, tp.data(), tp.size());
+        sc.tlasRootP = encP(0);
     }
     if (rc != RT_OK) { ctx->scene.reset(); ctx->sceneLoaded = false; return rc; }
     sc.nLights = nLights; sc.nPrims = nPrims; sc.nBlas = nBlas; sc.nTex = nTexels;
     ctx->singleBlas = tlas[0].leftRight == 0;
     ctx->sc = sc;
-    ctx->stackEntries = stackEntries; ctx->tlasDepth = tlasDepth;
+    ctx->stackEntries = stackEntries; ctx->tlasDepth = tlasDepth; ctx->nInterior = nInterior;
     rc = configure_traversal(ctx);
     if (rc != RT_OK) { ctx->scene.reset(); return rc; }
     ctx->sceneLoaded = true;
@@ -617,10 +636,25 @@ static int configure_traversal(RtCtx* ctx)
     // persistent-wavefront traversal: layout 1 and a TLAS whose root is a leaf (one BLAS)
     ctx->persist = ctx->layout == 1 && ctx->cfg.accel == RT_ACCEL_BVH2 && ctx->singleBlas && ctx->cfg.extend_variant != 2;
     ctx->persist4 = ctx->layout == 1 && ctx->cfg.accel == RT_ACCEL_BVH4 && ctx->singleBlas && ctx->cfg.extend_variant != 2;
-    if (ctx->persist || ctx->persist4) {
+    // ... and through a TLAS with several BLAS (BASELINE config 5): TLAS entries ride on the BLAS stack column, so the TLAS must be shallow
+    // (<= 8 levels: <= 256 instances in a balanced tree) and the pair-table ids must leave the three tag bits free; extend_variant 4 keeps
+    // the one-ray-per-lane nested loops (A/B runs)
+    ctx->persistTlas = ctx->layout == 1 && ctx->cfg.accel == RT_ACCEL_BVH2 && !ctx->singleBlas && ctx->cfg.extend_variant != 2 && ctx->cfg.extend_variant != 4 &&
+                       ctx->tlasDepth <= 8 && ctx->nInterior < (1 << 29);
+    // deep trees (an SBVH at alpha = 0: config 5's second BLAS has 63 levels): a full LDS column per lane would leave two workgroups per
+    // CU, so the column is capped and its deep end spills to global memory (rt355_kernels.h, stk_push / stk_pop)
+    ctx->spillCap = kSpillCap;
+    bool forceSpill = false;
+    if (const char* t = getenv("RT355_SPILL_CAP")) { const int v = atoi(t); if (v >= 6 && v <= 64) { ctx->spillCap = v; forceSpill = true; } }
+    ctx->spillStack = ctx->persistTlas && (tlas_stack_entries(ctx) > kFitSeven || forceSpill) && tlas_stack_entries(ctx) > ctx->spillCap &&
+                      !(getenv("RT355_NO_SPILL") && atoi(getenv("RT355_NO_SPILL")));
+    if (ctx->persistTlas && !ctx->spillStack && tlas_stack_entries(ctx) > RT_BVH4_STACK + 9) ctx->persistTlas = false;
+    if (ctx->persist || ctx->persist4 || ctx->persistTlas) {
         int perCU = 0; hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, ctx->cfg.device));
         if (ctx->persist) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_persist<false>, kBlock, stack_bytes(ctx)));
+        else if (ctx->persistTlas && ctx->spillStack) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (k_trace_persist_tlas<false, false, true>), kBlock, tlas_stack_bytes(ctx)));
+        else if (ctx->persistTlas) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_persist_tlas<false>, kBlock, tlas_stack_bytes(ctx)));
         else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_persist4<false>, kBlock, stack_bytes(ctx)));
         // the closest-hit instantiations use ~90 SGPRs, the any-hit ones ~100: the hardware admits 7 resp. 6 workgroups per CU where
         // the occupancy query may say more (see rt_create); a surplus workgroup would strand its static first chunk until another exits
@@ -639,14 +673,29 @@ static int configure_traversal(RtCtx* ctx)
         if (const char* t = getenv("RT355_TUNE")) { // "chunk,refill,inner,leafK[,blocksPerCU]" (tuning aid)
             int a = 0, b = 0, c = 0, l = 0, d = 0;
             int k = sscanf(t, "%d,%d,%d,%d,%d", &a, &b, &c, &l, &d);
-            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = ctx->tuneConnect = ctx->tune4 = PersistTune{ a, b, c, l, 0 };
+            if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = ctx->tuneConnect = ctx->tune4 = PersistTune{ a, b, c, l, 0, 0 };
             if (k == 5 && d > 0) ctx->persistGrid = ctx->persistGridConnect = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount);
         }
         if (const char* t = getenv("RT355_FIXED_CHUNKS")) { int a = 0, b = 0; if (sscanf(t, "%d,%d", &a, &b) == 2) { ctx->tune.fixedChunks = ctx->tune4.fixedChunks = a; ctx->tuneConnect.fixedChunks = b; } }   // extend, connect (tuning aid)
         if (const char* t = getenv("RT355_TUNE_CONNECT")) { // same fields, connect launches only
             int a = 0, b = 0, c = 0, l = 0;
-            if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l, 0 };
+            if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l, 0, 0 };
         }
+    }
+    if (ctx->persistTlas) {   // RT355_TLAS_FLAT="e,c": extend / connect of multi-BLAS scenes through the one-ray-per-lane branch of k_trace_persist_tlas (A/B runs)
+        if (const char* t = getenv("RT355_TLAS_FLAT")) { int a = 0, b = 0; if (sscanf(t, "%d,%d", &a, &b) == 2) { ctx->tune.flat = a; ctx->tuneConnect.flat = b; } }
+    }
+    ctx->q.spill = nullptr; ctx->q.spillStride = 0; ctx->q.stackCap = 0;
+    if (ctx->spillStack) {   // every SPILL launch runs on a persistent grid (bounce 0 too), so the global columns are bounded by the grids
+        const size_t stride = (size_t)std::max(ctx->persistGrid, ctx->persistGridConnect) * kBlock;
+        const size_t words = stride * (size_t)(tlas_stack_entries(ctx) - ctx->spillCap);
+        if (words > ctx->spillWords) {
+            if (ctx->dSpill) (void)hipFree(ctx->dSpill);
+            ctx->dSpill = nullptr; ctx->spillWords = 0;
+            if (hipMalloc((void**)&ctx->dSpill, words * sizeof(uint32_t)) != hipSuccess) return fail(RT_E_NOMEM, "hipMalloc of the spill stacks (%zu bytes) failed", words * sizeof(uint32_t));
+            ctx->spillWords = words;
+        }
+        ctx->q.spill = ctx->dSpill; ctx->q.spillStride = (uint32_t)stride; ctx->q.stackCap = (uint32_t)ctx->spillCap;
     }
     return RT_OK;
 }
@@ -666,7 +715,7 @@ extern "C" int rt_share_scene(RtCtx* ctx, RtCtx* from)
     ctx->sceneLoaded = false;
     ctx->scene = from->scene;
     ctx->sc = from->sc;
-    ctx->layout = from->layout; ctx->maxDepth2 = from->maxDepth2; ctx->stackEntries = from->stackEntries; ctx->singleBlas = from->singleBlas; ctx->tlasDepth = from->tlasDepth;
+    ctx->layout = from->layout; ctx->maxDepth2 = from->maxDepth2; ctx->stackEntries = from->stackEntries; ctx->singleBlas = from->singleBlas; ctx->tlasDepth = from->tlasDepth; ctx->nInterior = from->nInterior;
     const int rc = configure_traversal(ctx);
     if (rc != RT_OK) { ctx->scene.reset(); return rc; }
     ctx->sceneLoaded = true;
@@ -769,13 +818,22 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
 {
     int rc = need_scene(ctx, "rt_stage_extend"); if (rc) return rc;
     if (bounce < 0 || bounce > ctx->cfg.max_bounces) return fail(RT_E_INVALID, "rt_stage_extend: bounce %d outside [0, %d]", bounce, ctx->cfg.max_bounces);
-    if (ctx->persist || ctx->persist4) { // a queue head is good for one launch per frame; re-arm it if this stage is run again
+    if (ctx->persist || ctx->persist4 || ctx->persistTlas) { // a queue head is good for one launch per frame; re-arm it if this stage is run again
         if (ctx->cursorUsed[bounce]) HIPCHK(hipMemsetAsync(ctx->q.cursor + bounce, 0, sizeof(int32_t), ctx->stream));
         ctx->cursorUsed[bounce] = true;
     }
     const bool wantSteps = renderBVH != 0 || ctx->q.steps != nullptr;   // only then does the event loop keep the per-ray `steps`
     // bounce 0: primary rays are coherent and finish together, refilling buys nothing -> one ray per lane
-    if (ctx->persist4)
+    if (ctx->persistTlas) {
+        // bounce 0 with one workgroup per 256 rays: the kernel's short-queue branch = the nested one-ray-per-lane loops (coherent primary rays)
+        const dim3 g = bounce > 0 || ctx->spillStack ? dim3(ctx->persistGrid) : grid_for(ctx->nPix);
+        if (ctx->spillStack) {
+            if (wantSteps) LAUNCH(ctx, ST_EXTEND, (k_trace_persist_tlas<false, true, true>), g, tlas_stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+            else LAUNCH(ctx, ST_EXTEND, (k_trace_persist_tlas<false, false, true>), g, tlas_stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+        }
+        else if (wantSteps) LAUNCH(ctx, ST_EXTEND, (k_trace_persist_tlas<false, true>), g, tlas_stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+        else LAUNCH(ctx, ST_EXTEND, (k_trace_persist_tlas<false>), g, tlas_stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+    } else if (ctx->persist4)
         LAUNCH(ctx, ST_EXTEND, (k_trace_persist4<false>), bounce > 0 ? dim3(ctx->persistGrid) : grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune4);
     else if (ctx->persist && (bounce > 0 || ctx->cfg.extend_variant == 3)) {
         if (wantSteps) LAUNCH(ctx, ST_EXTEND, (k_trace_persist<false, false, true>), dim3(ctx->persistGrid), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
@@ -833,12 +891,16 @@ extern "C" int rt_stage_connect(RtCtx* ctx, int32_t b0, int32_t b1)
     int rc = need_scene(ctx, "rt_stage_connect"); if (rc) return rc;
     if (b0 < 0 || b1 < b0 || b1 >= ctx->cfg.max_bounces) return fail(RT_E_INVALID, "rt_stage_connect: bounce range [%d,%d] outside [0, %d)", b0, b1, ctx->cfg.max_bounces);
     const int cap = ctx->nPix * (b1 - b0 + 1);
-    if (ctx->persist || ctx->persist4) {
+    if (ctx->persist || ctx->persist4 || ctx->persistTlas) {
         const int ci = (RT_MAX_BOUNCES + 2) + b0;
         if (ctx->cursorUsed[ci]) HIPCHK(hipMemsetAsync(ctx->q.cursor + ci, 0, sizeof(int32_t), ctx->stream));
         ctx->cursorUsed[ci] = true;
     }
-    if (ctx->persist4)
+    if (ctx->persistTlas && ctx->spillStack)
+        LAUNCH(ctx, ST_CONNECT, (k_trace_persist_tlas<true, false, true>), dim3(ctx->persistGridConnect), tlas_stack_bytes(ctx), ctx->sc, ctx->q, b0, b1, 0, ctx->tuneConnect);
+    else if (ctx->persistTlas)
+        LAUNCH(ctx, ST_CONNECT, (k_trace_persist_tlas<true>), dim3(ctx->persistGridConnect), tlas_stack_bytes(ctx), ctx->sc, ctx->q, b0, b1, 0, ctx->tuneConnect);
+    else if (ctx->persist4)
         LAUNCH(ctx, ST_CONNECT, (k_trace_persist4<true>), dim3(ctx->persistGridConnect), stack_bytes(ctx), ctx->sc, ctx->q, b0, b1, 0, ctx->tuneConnect);
     else if (ctx->persist)
         LAUNCH(ctx, ST_CONNECT, (k_trace_persist<true>), dim3(ctx->persistGridConnect), stack_bytes(ctx), ctx->sc, ctx->q, b0, b1, 0, ctx->tuneConnect);
@@ -934,12 +996,12 @@ extern "C" int rt_write_accum(RtCtx* ctx, const RtFloat4* in)
     HIPCHK(hipMemcpy(ctx->q.accum, in, sizeof(float4) * (size_t)ctx->cfg.width * ctx->cfg.height, hipMemcpyHostToDevice));
     return RT_OK;
 }
-static int sum_table(RtCtx* ctx, const unsigned long long* dev, uint64_t out5[5])
+static int sum_table(RtCtx* ctx, const unsigned long long* dev, uint64_t out[kCtrCols])
 {
-    std::vector<unsigned long long> h((size_t)ctx->gridMax * 5);
+    std::vector<unsigned long long> h((size_t)ctx->gridMax * kCtrCols);
     HIPCHK(hipMemcpy(h.data(), dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 5; k++) out5[k] = 0;
-    for (size_t b = 0; b < (size_t)ctx->gridMax; b++) for (int k = 0; k < 5; k++) out5[k] += h[b * 5 + k];
+    for (int k = 0; k < kCtrCols; k++) out[k] = 0;
+    for (size_t b = 0; b < (size_t)ctx->gridMax; b++) for (int k = 0; k < kCtrCols; k++) out[k] += h[b * kCtrCols + k];
     return RT_OK;
 }
 extern "C" int rt_read_counters(RtCtx* ctx, RtCounters* out)
@@ -948,13 +1010,14 @@ extern "C" int rt_read_counters(RtCtx* ctx, RtCounters* out)
     HIPCHK(hipSetDevice(ctx->cfg.device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ev_collect(ctx);
-    uint64_t e[5], c[5];
+    uint64_t e[kCtrCols], c[kCtrCols];
     int rc = sum_table(ctx, ctx->q.ctrExtend, e); if (rc) return rc;
     rc = sum_table(ctx, ctx->q.ctrConnect, c); if (rc) return rc;
     memset(out, 0, sizeof *out);
     out->extend_rays = e[0]; out->extend_tlas_visits = e[1]; out->extend_inst_visits = e[2]; out->extend_node_visits = e[3]; out->extend_prim_tests = e[4];
     out->connect_rays = c[0]; out->connect_tlas_visits = c[1]; out->connect_inst_visits = c[2]; out->connect_node_visits = c[3]; out->connect_prim_tests = c[4];
     out->primary_rays = ctx->primaryRays; out->shadow_rays = c[0]; out->frames = ctx->frames;
+    out->extend_node_issues = e[5]; out->extend_leaf_issues = e[6]; out->connect_node_issues = c[5]; out->connect_leaf_issues = c[6];
     return RT_OK;
 }
 extern "C" int rt_reset_counters(RtCtx* ctx)
@@ -962,8 +1025,8 @@ extern "C" int rt_reset_counters(RtCtx* ctx)
     if (!ctx) return fail(RT_E_INVALID, "rt_reset_counters: null context");
     HIPCHK(hipSetDevice(ctx->cfg.device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemset(ctx->q.ctrExtend, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5));
-    HIPCHK(hipMemset(ctx->q.ctrConnect, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * 5));
+    HIPCHK(hipMemset(ctx->q.ctrExtend, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * kCtrCols));
+    HIPCHK(hipMemset(ctx->q.ctrConnect, 0, sizeof(unsigned long long) * (size_t)ctx->gridMax * kCtrCols));
     ctx->frames = 0; ctx->primaryRays = 0;
     return RT_OK;
 }
@@ -1152,33 +1215,28 @@ static void group_free(RtGroup* g)
     if (g->sum) (void)hipFree(g->sum);
     delete g;
 }
-// How many of the group's streams execute concurrently: one single-wave kernel that naps for ~200 us on every stream at once.
+// How many of the group's streams execute concurrently: one single-wave kernel that naps for ~1 ms, first on one stream, then on
+// every stream at once, both timed on the host.  Streams that share a hardware queue run their naps one after the other, so the
+// second figure is `depth` times the first, depth = the longest chain of serialised streams; the answer is lanes / depth.
 static int measure_concurrency(RtGroup* g)
 {
     const int n = (int)g->lane.size();
     if (n <= 1) return n;
     int rate = 0;
     if (hipDeviceGetAttribute(&rate, hipDeviceAttributeWallClockRate, g->lane[0]->cfg.device) != hipSuccess || rate <= 0) rate = 100000;   // kHz
-    const long long ticks = (long long)rate / 5;   // 200 us
+    const long long ticks = (long long)rate;        // 1 ms
     int* sink = (int*)g->lane[0]->q.fault;          // never written (ticks >= 0)
-    hipEvent_t a, b;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0;
-    float one = 0, all = 0;
-    for (int pass = 0; pass < 2; pass++) {   // pass 0 warms the code object up
-        (void)hipEventRecord(a, g->lane[0]->stream);
-        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, g->lane[0]->stream, ticks, sink);
-        (void)hipEventRecord(b, g->lane[0]->stream);
-        (void)hipEventSynchronize(b);
-        (void)hipEventElapsedTime(&one, a, b);
-    }
-    const auto t0 = std::chrono::steady_clock::now();
-    for (RtCtx* c : g->lane) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->stream, ticks, sink);
-    for (RtCtx* c : g->lane) (void)hipStreamSynchronize(c->stream);
-    all = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    auto run = [&](int streams) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int m = 0; m < streams; m++) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, g->lane[(size_t)m]->stream, ticks, sink);
+        for (int m = 0; m < streams; m++) (void)hipStreamSynchronize(g->lane[(size_t)m]->stream);
+        return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    (void)run(n);                                    // warms the code object up on every stream
+    const float one = run(1), all = run(n);
     if (one <= 0 || all <= 0) return 0;
-    const float rounds = std::max(1.0f, all / one);          // serialised streams take n naps, concurrent ones a little over one
-    return std::max(1, std::min(n, (int)std::lround((float)n / rounds)));
+    const int depth = std::max(1, std::min(n, (int)std::lround(all / one)));
+    return std::max(1, n / depth);
 }
 
 extern "C" int rt_group_create(const RtConfig* cfg, int32_t lanes, RtGroup** out)

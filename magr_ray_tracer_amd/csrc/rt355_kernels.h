@@ -55,6 +55,8 @@ struct DevScene {
     const float4*        tlasPairs;  // [nTlas][4]    TLAS interior node i: both child boxes + encoded children (leaf: kLeafBit | BLASidx), one 64-B fetch
     const float4*        instRecs;   // [nBlas][4]    rows 0..2 of invT + {encoded BLAS root (layout 1), bvhIdx}: one 64-B fetch per instance visit
     uint32_t             tlasRoot;   // encoded TLAS root (a leaf when the scene has one BLAS)
+    const float4*        tlasPairsP; // [nTlas][4]    the same records with the children in the tagged encoding of k_trace_persist_tlas (kTagTlas / kTagInst)
+    uint32_t             tlasRootP;  // TLAS root in that encoding
     const float4*        lightRecs;  // [nLights][8]  what NEE needs of light li in one place: objData[0..63], {objType, area}, emittance of its material
     const float4*        quads;      // [nNodes][8]  layout 1 of the BVH4: four child boxes + four encoded child entries (128 B)
     int32_t nLights, nPrims, nBlas, nTex;
@@ -77,8 +79,10 @@ struct DevQueues {
     uint32_t* seeds;   // one RNG stream per band slot
     float4* accum;     // full frame, indexed by global pixel index
     int32_t* steps;    // per-ray steps of the last extend (debug / heat map), may be null
-    unsigned long long* ctrExtend;  // [gridMax][5] per-block partial work counters
-    unsigned long long* ctrConnect; // [gridMax][5]
+    unsigned long long* ctrExtend;  // [gridMax][kCtrCols] per-block partial work counters
+    unsigned long long* ctrConnect; // [gridMax][kCtrCols]
+    uint32_t* spill;   // [spillEntries][spillStride] deep ends of the traversal stacks (SPILL instantiations), may be null
+    uint32_t spillStride, stackCap;   // lanes of the largest SPILL launch; LDS entries per lane of those launches
     int32_t nPix, firstPixel, width, height;
 };
 // k_shade hands its tiles out by ticket.  ONE counter: any running workgroup draws the smallest tile not drawn yet, so the ordered scan
@@ -117,12 +121,28 @@ RT_FORCEINLINE float4 cross4(float4 a, float4 b)
 {
     return mk4(__fmaf_rn(a.y, b.z, b.y * (-a.z)), __fmaf_rn(a.z, b.x, b.z * (-a.x)), __fmaf_rn(a.x, b.y, b.x * (-a.y)), 0.0f);
 }
+// -DRT355_REF_BUILTINS (a second library, librt355_refb.so, built by build.py; NOT the shipped default): the builtins below evaluate the
+// very instruction sequences ROCm's OpenCL library gives the reference's kernels - normalize() = v * rsqrt(dot) with the hardware
+// v_rsq_f32 (opencl.bc _Z9normalizeDv4_f -> __ocml_rsqrt_f32), length() = the hardware v_sqrt_f32 (llvm.sqrt with !fpmath 3 ulp in
+// _Z6lengthDv4_f), exp / sin / cos / acospi / atan2pi = the same ocml bitcode functions the OpenCL builtins resolve to (HIP links the same
+// ocml.bc with the same control constants: correctly rounded sqrt on, denormals on, no unsafe math).  With them the HIP path is held to
+// the reference's own kernels WITHOUT the few-ulp allowance of DESIGN.md section 2, on uncurated frames (tests/test_gpu_reference.py).
+// The default build keeps IEEE 1/sqrt and the Cephes sequences: those are what a CPU (the oracle) can reproduce bit for bit.
+#ifdef RT355_REF_BUILTINS
+extern "C" __device__ float __ocml_acospi_f32(float);
+extern "C" __device__ float __ocml_atan2pi_f32(float, float);
+RT_FORCEINLINE float rt_len_sqrt(float d) { return __builtin_amdgcn_sqrtf(d); }
+RT_FORCEINLINE float rt_rsqrt(float d) { return __ocml_rsqrt_f32(d); }
+#else
+RT_FORCEINLINE float rt_len_sqrt(float d) { return sqrtf(d); }
+RT_FORCEINLINE float rt_rsqrt(float d) { return 1.0f / sqrtf(d); }
+#endif
 RT_FORCEINLINE float length4(float4 v)
 {
     float d = dot4(v, v);
-    if (d < 1.17549435e-38f) { float4 s = muls(v, 0x1p+86f); return sqrtf(dot4(s, s)) * 0x1p-86f; }
-    if (d == INFINITY) { float4 s = muls(v, 0x1p-66f); return sqrtf(dot4(s, s)) * 0x1p+66f; }
-    return sqrtf(d);
+    if (d < 1.17549435e-38f) { float4 s = muls(v, 0x1p+86f); return rt_len_sqrt(dot4(s, s)) * 0x1p-86f; }
+    if (d == INFINITY) { float4 s = muls(v, 0x1p-66f); return rt_len_sqrt(dot4(s, s)) * 0x1p+66f; }
+    return rt_len_sqrt(d);
 }
 RT_FORCEINLINE float sel_inf(float x) { return copysignf(isinf(x) ? 1.0f : 0.0f, x); }
 RT_FORCEINLINE float4 normalize4(float4 v)
@@ -134,7 +154,7 @@ RT_FORCEINLINE float4 normalize4(float4 v)
         v = muls(v, 0x1p-66f); d = dot4(v, v);
         if (d == INFINITY) { v = mk4(sel_inf(v.x), sel_inf(v.y), sel_inf(v.z), sel_inf(v.w)); d = dot4(v, v); }
     }
-    float r = 1.0f / sqrtf(d);
+    float r = rt_rsqrt(d);
     return muls(v, r);
 }
 
@@ -145,6 +165,11 @@ RT_FORCEINLINE float4 normalize4(float4 v)
 // Cephes algorithms (S. Moshier: expf.c, sinf.c, asinf.c, atanf.c) as plain sequences of IEEE + - * / sqrt - transcribed separately
 // here and in oracle/oracle.c - and agree bit for bit on every scene.  They are within 2 ulp of the correctly rounded value, i.e. as
 // close to the reference's builtins as those are to each other.
+#ifdef RT355_REF_BUILTINS
+RT_FORCEINLINE float rt_expf(float x) { return __ocml_exp_f32(x); }
+RT_FORCEINLINE float rt_sinf(float x) { return __ocml_sin_f32(x); }
+RT_FORCEINLINE float rt_cosf(float x) { return __ocml_cos_f32(x); }
+#else
 RT_FORCEINLINE float rt_expf(float x)
 {
     if (x != x) return x;
@@ -261,6 +286,7 @@ RT_FORCEINLINE float rt_atan2f(float y, float x)
     if (x < 0.0f) z = signbit(y) ? z - 3.14159265358979323846f : z + 3.14159265358979323846f;
     return z;
 }
+#endif
 
 // ------------------------------------------------------------------ RNG (util.cl:50-59)
 RT_FORCEINLINE uint32_t rng_next(uint32_t& s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }
@@ -275,7 +301,8 @@ struct TRay {
     float ox, oy, oz, dx, dy, dz, rx, ry, rz;
     float t; int prim; float u, v;
 };
-struct WorkCtr { uint32_t tlas, inst, node, prim; };
+struct WorkCtr { uint32_t tlas, inst, node, prim, nodeIss = 0, leafIss = 0; };   // nodeIss / leafIss: wave-level issues of the node path / the triangle path by the event loops (x 64 lanes = the slots those events had)
+static constexpr int kCtrCols = 7;
 
 RT_FORCEINLINE float slab(const TRay& r, float4 bmin, float4 bmax) // bvh.cl:3-12
 {
@@ -689,21 +716,21 @@ RT_FORCEINLINE int traverse_tlas(const DevScene& sc, TRay& r, uint32_t* stk, Wor
 
 // Sum a lane's work counters over the workgroup and add them to this block's row of the
 // per-block partial table (no atomics: one row per blockIdx, launches are stream-ordered).
-RT_FORCEINLINE void flush_counters(unsigned long long* table, uint32_t rays, const WorkCtr& wc, uint32_t* red /* >= 5*4 words LDS */)
+RT_FORCEINLINE void flush_counters(unsigned long long* table, uint32_t rays, const WorkCtr& wc, uint32_t* red /* >= kCtrCols*4 words LDS */)
 {
-    uint32_t v[5] = { rays, wc.tlas, wc.inst, wc.node, wc.prim };
+    uint32_t v[kCtrCols] = { rays, wc.tlas, wc.inst, wc.node, wc.prim, wc.nodeIss, wc.leafIss };
 #pragma unroll
-    for (int k = 0; k < 5; k++)
+    for (int k = 0; k < kCtrCols; k++)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __syncthreads(); // LDS stack columns are dead past this point
-    if (lane == 0) for (int k = 0; k < 5; k++) red[wave * 5 + k] = v[k];
+    if (lane == 0) for (int k = 0; k < kCtrCols; k++) red[wave * kCtrCols + k] = v[k];
     __syncthreads();
-    if (threadIdx.x < 5) {
+    if (threadIdx.x < kCtrCols) {
         unsigned long long s = 0;
-        for (int w = 0; w < kBlock / 64; w++) s += red[w * 5 + threadIdx.x];
-        table[(size_t)blockIdx.x * 5 + threadIdx.x] += s;
+        for (int w = 0; w < kBlock / 64; w++) s += red[w * kCtrCols + threadIdx.x];
+        table[(size_t)blockIdx.x * kCtrCols + threadIdx.x] += s;
     }
 }
 
@@ -805,7 +832,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int
 static constexpr int kTpWaves = 8192;
 __device__ unsigned long long g_tp[9][kTpWaves][4];
 #endif
-struct PersistTune { int chunk, refill, inner, leafK, fixedChunks; };   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path, chunks dealt round-robin instead of dequeued
+struct PersistTune { int chunk, refill, inner, leafK, fixedChunks, flat = 0; };   // flat: k_trace_persist_tlas runs every queue through its one-ray-per-lane branch, 64 rays per wave and round (short traversals: config 5's open scene)   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path, chunks dealt round-robin instead of dequeued
 
 // Short queue (late bounces, and bounce 0 when it is launched with one workgroup per 256 rays): every wave gets at most one 64-ray chunk
 // and nothing is left to refill from, so run the plain one-ray-per-lane loop, which has less per-step overhead than the refill machine.
@@ -867,7 +894,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
 
     WorkCtr wc = { 0, 0, 0, 0 };
     uint32_t rays = 0;
-    uint32_t wRays = 0, wNode = 0, wPrim = 0;    // this wave's work (wave-uniform)
+    uint32_t wRays = 0, wNode = 0, wPrim = 0, wNodeIss = 0, wLeafIss = 0;    // this wave's work (wave-uniform): events by kind, and how often each path was issued
     TRay r; r.t = 0; r.prim = -1; r.u = r.v = 0; r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.rx = r.ry = r.rz = 0;
     uint32_t cur = 0, sp = 0;
     int slot = -1, steps = 0;
@@ -937,9 +964,9 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
             if ((lm | im) == 0ull) break;
             const bool doLeaf = im == 0ull || __popcll(lm) >= kLeafK;
             bool done = false, occluded = false;
-            if (!doLeaf) wNode += (uint32_t)__popcll(im);
+            if (!doLeaf) { wNode += (uint32_t)__popcll(im); wNodeIss++; }
             if (doLeaf) {
-                wPrim += (uint32_t)__popcll(lm);
+                wPrim += (uint32_t)__popcll(lm); wLeafIss++;
                 if (atLeaf) {
                     const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
                     test_tri_packed(sc, first, r);
@@ -990,7 +1017,305 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
 #ifdef RT355_TAIL_PROBE
     TAIL_PROBE_EXIT()
 #endif
-    if (lane == 0) { rays = wRays; wc.inst = wRays; wc.node = wNode; wc.prim = wPrim; }   // the wave's totals enter the reduction once
+    if (lane == 0) { rays = wRays; wc.inst = wRays; wc.node = wNode; wc.prim = wPrim; wc.nodeIss = wNodeIss; wc.leafIss = wLeafIss; }   // the wave's totals enter the reduction once
+    flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
+}
+
+// ------------------------------------------------------------------ k_trace_persist_tlas: persistent wavefronts through a multi-BLAS TLAS (BVH2, layout 1)
+// BASELINE config 5 (two BLAS under a TLAS; tlas.cl:9-77).  Same work distribution and event loop as k_trace_persist; what is new is
+// that a lane's traversal has two levels.  Everything a lane still has to visit lives on ONE LDS stack column, the entries tagged by
+// the space they belong to:
+//     bit 31 set                      BLAS leaf        count << 24 | first          (as in k_trace_persist)
+//     bits 31..29 = 000               BLAS interior    id in the dense pair table
+//     bits 31..29 = 010  (kTagTlas)   TLAS interior    id in tlasPairsP
+//     bits 31..29 = 011  (kTagInst)   TLAS leaf        instance id
+// A lane is either in TLAS space (world ray in its registers, spBase = 0) or inside an instance (object-space ray in its registers;
+// spBase = the stack height at entry, so "sp == spBase" means the instance's tree is exhausted).  The ray is transformed ONCE, at the
+// moment the lane enters the instance (transformRay, tlas.cl:3-8, the arithmetic of traverse_instance), kept in registers over all
+// events of that instance, and the world ray is fetched back from the queue when the lane leaves it (tlas.cl:21-23 restores a 128-byte
+// backup; <= nBlas times per ray).  TLAS interior nodes go through the same code path as BLAS interior nodes - one 64-byte record,
+// two slab tests, near child first, far child pushed (tlas.cl:48-75 is bvh.cl:41-52 with other names) - only the table differs.
+// Visit order, pruning distances (tLight = ray.t on entering the level: tlas.cl:31, bvh.cl:19), `steps` (BLAS levels only: tlas.cl:44)
+// and all work counters are those of traverse_tlas, so hits and counters are bit-identical to the one-ray-per-lane kernels.
+// connect (OCC): inside an instance the any-hit order of k_trace_persist (later exit first); TLAS nodes keep the reference's
+// near-first order, so the TLAS-visit and instance-visit counts stay the reference's (which instance is entered first decides whether
+// the second one is entered at all).
+static constexpr uint32_t kTagTlas = 0x40000000u, kTagInst = 0x60000000u, kTagMask = 0xe0000000u, kIdMask = 0x1fffffffu;
+RT_FORCEINLINE bool slab_both(const TRay& r, float4 bmin, float4 bmax, float& tminOut, float& tmaxOut)
+{
+    float tx1 = (bmin.x - r.ox) * r.rx, tx2 = (bmax.x - r.ox) * r.rx;
+    float tmin = fminf(tx1, tx2), tmax = fmaxf(tx1, tx2);
+    float ty1 = (bmin.y - r.oy) * r.ry, ty2 = (bmax.y - r.oy) * r.ry;
+    tmin = fmaxf(tmin, fminf(ty1, ty2)); tmax = fminf(tmax, fmaxf(ty1, ty2));
+    float tz1 = (bmin.z - r.oz) * r.rz, tz2 = (bmax.z - r.oz) * r.rz;
+    tmin = fmaxf(tmin, fminf(tz1, tz2)); tmax = fminf(tmax, fmaxf(tz1, tz2));
+    tminOut = tmin; tmaxOut = tmax;
+    return tmax >= tmin && tmin < r.t && tmax > 0;
+}
+// SPILL: the LDS column holds the first q.stackCap entries of a lane's stack, deeper ones live in a global per-lane column (q.spill,
+// entry-major so that the lanes of a wave write neighbouring words).  An SBVH at alpha = 0 gets DEEP (config 5's terrarium: 63 levels):
+// 64 entries x 1 KB per workgroup would leave two workgroups per CU; capped at 20 entries seven fit, and the traversal - a chain of
+// dependent fetches that lives on occupancy - rarely goes deeper than the cap (near child first keeps one pending sibling per level
+// actually forked).  The two extra branches per push / pop cost a scene that does not need them ~9 % (EXPERIMENTS.md (19)), so the
+// instantiation is chosen per scene at upload.
+template <bool SPILL> RT_FORCEINLINE void stk_push(uint32_t* stk, const DevQueues& q, uint32_t gl, uint32_t& sp, uint32_t e)
+{
+    if (!SPILL || sp < q.stackCap) stk[sp * kBlock + threadIdx.x] = e;
+    else q.spill[(size_t)(sp - q.stackCap) * q.spillStride + gl] = e;
+    sp++;
+}
+template <bool SPILL> RT_FORCEINLINE uint32_t stk_pop(const uint32_t* stk, const DevQueues& q, uint32_t gl, uint32_t& sp)
+{
+    --sp;
+    return (!SPILL || sp < q.stackCap) ? stk[sp * kBlock + threadIdx.x] : q.spill[(size_t)(sp - q.stackCap) * q.spillStride + gl];
+}
+template <bool OCC, bool STEPS = false, bool SPILL = false>
+__global__ __launch_bounds__(kBlock) void k_trace_persist_tlas(DevScene sc, DevQueues q, int b0, int b1, int renderBVH, PersistTune tune)
+{
+    const int kChunk = tune.chunk, kRefill = tune.refill, kInner = tune.inner, kLeafK = tune.leafK;
+    extern __shared__ uint32_t stk[];
+    const int lane = threadIdx.x & 63;
+    const int qFirst = OCC ? q.nShadow[b0] : 0;
+    const int n = OCC ? q.nShadow[b1 + 1] - qFirst : q.nRays[b0];
+    int32_t* cursor = q.cursor + (OCC ? (RT_MAX_BOUNCES + 2) + b0 : b0);
+    const int nWaves = gridDim.x * (kBlock / 64), waveId = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;    // this lane's column of the spill stack
+
+    if (n <= nWaves * 64 || tune.flat) {
+        // Short queue (late bounces; bounce 0 when launched with one workgroup per 256 rays): one ray per lane and nothing to refill
+        // from, so every lane just runs its own state machine to the end - the same states and the same single stack column as the
+        // event loop below (world ray re-fetched on leaving an instance instead of a nine-register backup), without the wave-level
+        // path selection.  tune.flat: ANY queue this way, the persistent grid striding over it 64 rays per wave and round - scenes whose
+        // rays take a dozen events (an open scene: most rays leave through the TLAS root or end on the floor) finish before the event
+        // loop's bookkeeping pays, but still want the seven workgroups per CU that the capped stack column allows.
+        WorkCtr wc = { 0, 0, 0, 0 };
+        uint32_t rays = 0;
+        for (int idx = waveId * 64 + lane; idx < n; idx += nWaves * 64) {
+            TRay r;
+            float tmax;
+            {
+                float4 O, D;
+                if (OCC) { const float4 a = q.sA[qFirst + idx], b = q.sB[qFirst + idx]; O = a; D = b; tmax = a.w; }
+                else { O = q.O[b0 & 1][idx]; D = q.D[b0 & 1][idx]; tmax = kFar; }
+                r.ox = O.x; r.oy = O.y; r.oz = O.z; r.dx = D.x; r.dy = D.y; r.dz = D.z;
+                r.rx = 1.0f / D.x; r.ry = 1.0f / D.y; r.rz = 1.0f / D.z;
+            }
+            r.t = tmax; r.prim = -1; r.u = 0.0f; r.v = 0.0f;
+            rays++;
+            uint32_t cur = sc.tlasRootP, sp = 0, spBase = 0;
+            bool inInst = false, occluded = false;
+            float tLight = tmax;
+            int steps = 0;
+            for (;;) {
+                bool needPop = false;
+                if (cur & kLeafBit) {
+                    const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
+                    for (uint32_t i = 0; i < count; i++) {
+                        wc.prim++;
+                        test_tri_packed(sc, first + i, r);
+                        if (OCC && r.t < tLight) { occluded = true; break; }
+                    }
+                    if (OCC && occluded) break;
+                    needPop = true;
+                } else if ((cur & kTagMask) == kTagInst) {
+                    const float4* ir = sc.instRecs + (size_t)(cur & kIdMask) * 4;
+                    const float4 t0 = ir[0], t1 = ir[1], t2 = ir[2], t3 = ir[3];
+                    const float4 Dv = mk4(r.dx, r.dy, r.dz, 0.0f), Ov = mk4(r.ox, r.oy, r.oz, 0.0f);
+                    r.dx = dot3(mk4(t0.x, t0.y, t0.z, 0), Dv); r.dy = dot3(mk4(t1.x, t1.y, t1.z, 0), Dv); r.dz = dot3(mk4(t2.x, t2.y, t2.z, 0), Dv);
+                    r.ox = dot3(mk4(t0.x, t0.y, t0.z, 0), Ov) + t0.w; r.oy = dot3(mk4(t1.x, t1.y, t1.z, 0), Ov) + t1.w;
+                    r.oz = dot3(mk4(t2.x, t2.y, t2.z, 0), Ov) + t2.w;
+                    r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
+                    wc.inst++;
+                    cur = __float_as_uint(t3.x);
+                    spBase = sp; inInst = true; tLight = r.t;
+                    continue;
+                } else {
+                    const bool isT = (cur & kTagTlas) != 0u;
+                    if (isT) wc.tlas++; else wc.node++;
+                    const float4* p = (isT ? sc.tlasPairsP : sc.pairs) + (size_t)(cur & kIdMask) * 4;
+                    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                    uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
+                    if (OCC) {
+                        float n1, x1, n2, x2;
+                        const bool h1 = slab_both(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f), n1, x1);
+                        const bool h2 = slab_both(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f), n2, x2);
+                        if (h1 && h2) { const bool firstIs2 = isT ? (n2 < n1) : (x2 > x1); cur = firstIs2 ? e2 : e1; stk_push<SPILL>(stk, q, gl, sp, firstIs2 ? e1 : e2); }
+                        else if (h1 || h2) cur = h1 ? e1 : e2;
+                        else needPop = true;
+                    } else {
+                        float d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
+                        float d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
+                        if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t e = e1; e1 = e2; e2 = e; }
+                        if (d1 >= tLight) needPop = true;
+                        else {
+                            if (!isT) steps++;
+                            cur = e1;
+                            if (d2 < tLight) { stk_push<SPILL>(stk, q, gl, sp, e2); if (!isT) steps++; }
+                        }
+                    }
+                }
+                if (needPop) {
+                    if (inInst && sp == spBase) {
+                        float4 O, D;
+                        if (OCC) { const float4 a = q.sA[qFirst + idx], b = q.sB[qFirst + idx]; O = a; D = b; tLight = a.w; }
+                        else { O = q.O[b0 & 1][idx]; D = q.D[b0 & 1][idx]; tLight = kFar; }
+                        r.ox = O.x; r.oy = O.y; r.oz = O.z; r.dx = D.x; r.dy = D.y; r.dz = D.z;
+                        r.rx = 1.0f / D.x; r.ry = 1.0f / D.y; r.rz = 1.0f / D.z;
+                        inInst = false; spBase = 0;
+                    }
+                    if (sp == 0) break;
+                    cur = stk_pop<SPILL>(stk, q, gl, sp);
+                }
+            }
+            if (OCC) { if (occluded) q.sC[qFirst + idx] = splat(0.0f); }
+            else {
+                q.hit[idx] = mk4(r.t, __int_as_float(r.prim), r.u, r.v);
+                if (q.steps) q.steps[idx] = steps;
+                if (renderBVH) q.accum[q.firstPixel + idx] = splat((float)(uint32_t)steps / 255.f);
+            }
+        }
+        flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
+        return;
+    }
+
+    uint32_t wRays = 0, wNode = 0, wPrim = 0, wTlas = 0, wInst = 0, wNodeIss = 0, wLeafIss = 0;    // this wave's work (wave-uniform)
+    TRay r; r.t = 0; r.prim = -1; r.u = r.v = 0; r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.rx = r.ry = r.rz = 0;
+    uint32_t cur = 0, sp = 0, spBase = 0;
+    bool inInst = false;
+    int slot = -1, steps = 0;
+    float tLight = 0;
+    int chunkNext = min(waveId * kChunk, n), chunkEnd = min(waveId * kChunk + kChunk, n);   // wave-uniform
+    bool exhausted = false;
+    int round = 0;
+
+    // the world ray of queue slot `idx` into r (k_extend / k_connect: rD = 1 / D, three IEEE divides)
+    auto world_ray = [&](int idx, float& tmax) {
+        float4 O, D;
+        if (OCC) { const float4 a = q.sA[qFirst + idx], b = q.sB[qFirst + idx]; O = a; D = b; tmax = a.w; }
+        else { O = q.O[b0 & 1][idx]; D = q.D[b0 & 1][idx]; tmax = kFar; }
+        r.ox = O.x; r.oy = O.y; r.oz = O.z; r.dx = D.x; r.dy = D.y; r.dz = D.z;
+        r.rx = 1.0f / D.x; r.ry = 1.0f / D.y; r.rz = 1.0f / D.z;
+    };
+
+    for (;;) {
+        const unsigned long long idleMask = __ballot(slot < 0);
+        const int nIdle = __popcll(idleMask);
+        if (nIdle == 64 && exhausted && chunkNext >= chunkEnd) break;
+        if (nIdle >= kRefill && !(exhausted && chunkNext >= chunkEnd)) {
+            if (chunkNext >= chunkEnd) {
+                int c = 0;
+                if (tune.fixedChunks) { round++; c = round * nWaves * kChunk + waveId * kChunk; }
+                else {
+                    if (lane == 0) c = atomicAdd(cursor, kChunk);
+                    c = __shfl(c, 0, 64) + nWaves * kChunk;
+                }
+                chunkNext = c; chunkEnd = min(c + kChunk, n);
+                if (c >= n) { exhausted = true; chunkNext = chunkEnd = 0; }
+            }
+            if (chunkNext < chunkEnd) {
+                const int rank = __popcll(idleMask & ((1ull << lane) - 1ull));
+                const int idx = chunkNext + rank;
+                if (slot < 0 && idx < chunkEnd) {
+                    float tmax;
+                    world_ray(idx, tmax);
+                    r.t = tmax; r.prim = -1; r.u = 0.0f; r.v = 0.0f;
+                    tLight = tmax; cur = sc.tlasRootP; sp = 0; spBase = 0; inInst = false; steps = 0; slot = idx;
+                }
+                wRays += (uint32_t)min(nIdle, chunkEnd - chunkNext);
+                chunkNext = min(chunkNext + nIdle, chunkEnd);
+            }
+        }
+#pragma unroll 1
+        for (int it = 0; it < kInner; it++) {
+            const bool act = slot >= 0, atLeaf = act && (cur & kLeafBit) != 0u;
+            const bool atInst = act && (cur & kTagMask) == kTagInst;
+            const bool atNode = act && !atLeaf && !atInst;
+            const unsigned long long lm = __ballot(atLeaf), im = __ballot(atNode), xm = __ballot(atInst);
+            if ((lm | im | xm) == 0ull) break;
+            if (xm != 0ull) {
+                // enter an instance (instanceIntersect, tlas.cl:9-26): rare (<= nBlas per ray) and short, so it goes first and alone
+                wInst += (uint32_t)__popcll(xm);
+                if (atInst) {
+                    const float4* ir = sc.instRecs + (size_t)(cur & kIdMask) * 4;
+                    const float4 t0 = ir[0], t1 = ir[1], t2 = ir[2], t3 = ir[3];
+                    const float4 Dv = mk4(r.dx, r.dy, r.dz, 0.0f), Ov = mk4(r.ox, r.oy, r.oz, 0.0f);
+                    r.dx = dot3(mk4(t0.x, t0.y, t0.z, 0), Dv); r.dy = dot3(mk4(t1.x, t1.y, t1.z, 0), Dv); r.dz = dot3(mk4(t2.x, t2.y, t2.z, 0), Dv);
+                    r.ox = dot3(mk4(t0.x, t0.y, t0.z, 0), Ov) + t0.w; r.oy = dot3(mk4(t1.x, t1.y, t1.z, 0), Ov) + t1.w;
+                    r.oz = dot3(mk4(t2.x, t2.y, t2.z, 0), Ov) + t2.w;
+                    r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
+                    cur = __float_as_uint(t3.x);          // encoded BLAS root (interior id or leaf)
+                    spBase = sp; inInst = true; tLight = r.t;   // intersectBVH2 prunes against ray.t on entry (bvh.cl:19)
+                }
+                continue;
+            }
+            const bool doLeaf = im == 0ull || __popcll(lm) >= kLeafK;
+            bool done = false, occluded = false, needPop = false;
+            if (doLeaf) {
+                wPrim += (uint32_t)__popcll(lm); wLeafIss++;
+                if (atLeaf) {
+                    const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
+                    test_tri_packed(sc, first, r);
+                    if (OCC && r.t < tLight) { done = true; occluded = true; }
+                    else if (count > 1) cur = kLeafBit | ((count - 1) << 24) | (first + 1);
+                    else needPop = true;
+                }
+            } else {
+                wNodeIss++;
+                const bool isT = (cur & kTagTlas) != 0u;
+                const unsigned long long tm = __ballot(atNode && isT);
+                wTlas += (uint32_t)__popcll(tm); wNode += (uint32_t)(__popcll(im) - __popcll(tm));
+                if (atNode) {
+                    const float4* p = (isT ? sc.tlasPairsP : sc.pairs) + (size_t)(cur & kIdMask) * 4;
+                    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                    uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
+                    if (OCC) {
+                        float n1, x1, n2, x2;
+                        const bool h1 = slab_both(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f), n1, x1);
+                        const bool h2 = slab_both(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f), n2, x2);
+                        if (h1 && h2) {
+                            const bool firstIs2 = isT ? (n2 < n1) : (x2 > x1);   // TLAS: the reference's near-first (tlas.cl:58-63); BLAS: later exit first
+                            cur = firstIs2 ? e2 : e1; stk_push<SPILL>(stk, q, gl, sp, firstIs2 ? e1 : e2);
+                        }
+                        else if (h1 || h2) cur = h1 ? e1 : e2;
+                        else needPop = true;
+                    } else {
+                        float d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
+                        float d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
+                        if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t e = e1; e1 = e2; e2 = e; }
+                        if (d1 >= tLight) needPop = true;
+                        else {
+                            if (STEPS && !isT) steps++;
+                            cur = e1;
+                            if (d2 < tLight) { stk_push<SPILL>(stk, q, gl, sp, e2); if (STEPS && !isT) steps++; }
+                        }
+                    }
+                }
+            }
+            if (needPop) {
+                if (inInst && sp == spBase) {   // the instance's tree is exhausted: back to world space (tlas.cl:21-23)
+                    float tmax;
+                    world_ray(slot, tmax);
+                    tLight = tmax; inInst = false; spBase = 0;   // the TLAS level prunes against the ray.t of ITS entry (tlas.cl:31)
+                }
+                if (sp == 0) done = true;
+                else cur = stk_pop<SPILL>(stk, q, gl, sp);
+            }
+            if (done) {
+                if (OCC) { if (occluded) q.sC[qFirst + slot] = splat(0.0f); }
+                else {
+                    q.hit[slot] = mk4(r.t, __int_as_float(r.prim), r.u, r.v);
+                    if (STEPS) {
+                        if (q.steps) q.steps[slot] = steps;
+                        if (renderBVH) q.accum[q.firstPixel + slot] = splat((float)(uint32_t)steps / 255.f);
+                    }
+                }
+                slot = -1;
+            }
+        }
+    }
+    WorkCtr wc = { 0, 0, 0, 0 };
+    uint32_t rays = 0;
+    if (lane == 0) { rays = wRays; wc.tlas = wTlas; wc.inst = wInst; wc.node = wNode; wc.prim = wPrim; wc.nodeIss = wNodeIss; wc.leafIss = wLeafIss; }
     flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
 }
 
@@ -1188,8 +1513,13 @@ RT_FORCEINLINE float4 albedo_of(const DevScene& sc, const RtPrimitive* prim, con
             int x = f2i_gpu(ux * (float)texW), y = f2i_gpu(uy * (float)texH);
             albedo = texel(sc, (long long)texIdx + x + (long long)y * texW);
         } else if (type == RT_PRIM_SPHERE) {
+#ifdef RT355_REF_BUILTINS
+            float ux = (1.0f + __ocml_atan2pi_f32(ray.N.z, ray.N.x)) * 0.5f;   // primitives.cl:130 (int + float is a float add; * 0.5 is exact in any precision)
+            float uy = __ocml_acospi_f32(ray.N.y);                             // :131
+#else
             float ux = (float)((1 + rt_atan2f(ray.N.z, ray.N.x) / 3.14159265358979323846) * 0.5);
             float uy = rt_acosf(ray.N.y) / 3.14159265358979323846f;
+#endif
             int x = f2i_gpu(ux * (float)texW), y = f2i_gpu(uy * (float)texH);
             albedo = texel(sc, (long long)texIdx + x + (long long)y * texW);
         } else {

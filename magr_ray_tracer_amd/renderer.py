@@ -17,8 +17,8 @@ class RtError(RuntimeError):
 class Device:
     def __init__(self, width, height, y0=0, y1=None, shading=_lib.SHADING_NEE, sampling=_lib.SAMPLING_COSINE,
                  accel=_lib.ACCEL_BVH2, russian_roulette=True, filter_fireflies=True, max_bounces=_lib.MAX_BOUNCES,
-                 device=0, profile=False, extend_variant=0, shade_blocks_per_cu=0, persist_blocks_per_cu=0):
-        self._lib = _lib.device_lib()
+                 device=0, profile=False, extend_variant=0, shade_blocks_per_cu=0, persist_blocks_per_cu=0, lib=None):
+        self._lib = _lib.device_lib(lib)      # lib="refb": the build with the reference's OpenCL builtin sequences (tests only)
         cfg = np.zeros((), dtype=_lib.Config)
         cfg["width"], cfg["height"], cfg["y0"], cfg["y1"] = width, height, y0, height if y1 is None else y1
         cfg["max_bounces"], cfg["shading"], cfg["sampling"], cfg["accel"] = max_bounces, shading, sampling, accel
@@ -89,6 +89,10 @@ class Device:
         k = self.kernel_info()
         if k["persist4"]:
             return "k_trace_persist4<false>"
+        if k["persist"] == 3:
+            return "k_trace_persist_tlas<false, false, true> (LDS stack of %d entries per lane, deeper entries in global memory)" % k["stack_entries"]
+        if k["persist"] == 2:
+            return "k_trace_persist_tlas<false> (bounce 0: its one-ray-per-lane branch)"
         if k["persist"]:
             return "k_trace_persist<false> (bounce 0: <false, true>, node records of wave-uniform visits through the scalar cache)"
         return "k_extend<%s, %d>" % ("RT_ACCEL_BVH4" if self.accel == _lib.ACCEL_BVH4 else "RT_ACCEL_BVH2", k["layout"])

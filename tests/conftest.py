@@ -17,6 +17,7 @@ def _native_libs():
     """Make sure the in-tree native libraries exist (no-op when they are up to date)."""
     from magr_ray_tracer_amd import build
     build.build_device()
+    build.build_device_refb()
     build.build_host()
     build.build_oracle()
     build.build_ref()

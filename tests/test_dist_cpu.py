@@ -91,6 +91,85 @@ def test_two_ranks_gloo_reduce(tmp_path, shard):
         assert got[p0["y0"]:p0["y1"]].any() and got[p1["y0"]:p1["y1"]].any()
 
 
+WORKER8 = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import numpy as np, torch, torch.distributed as dist
+    torch.set_num_threads(1)
+    from magr_ray_tracer_amd import dist as rdist, scenes
+    from oracle.oracle_py import Oracle, seed_stream
+    shard, lanes, total = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    rank, world, local = rdist.init_process_group("gloo")
+    W, H = 40, 24
+    s, view = scenes.cube_scene()
+    sa = s.arrays()
+    cam = scenes.camera_for(view, W, H)
+    o = Oracle(sa, W, H)
+    acc = np.zeros((H, W, 4), np.float32)
+    # a FIXED `total`-spp image: the sample plan splits the samples over ranks x lanes, the band plans split the rows over the ranks and
+    # the samples of a band over its lanes (bench.py --total-steps)
+    mine = rdist.rank_frames(total, rank, world) if shard == "samples" else total
+    for m, frames in enumerate(rdist.lane_frames(mine, lanes)):
+        for p in rdist.plans(shard, W, H, rank, world, m, lanes, band_rows=2 if shard == "ibands" else None):
+            if frames:
+                o.render(cam, frames, accum=acc, seeds=seed_stream(p["seed_first"], p["seed_count"]), y0=p["y0"], y1=p["y1"])
+    t = torch.from_numpy(acc)
+    rdist.reduce_accumulator(t)
+    if rank == 0:
+        np.save(sys.argv[4], t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+@pytest.mark.parametrize("shard", ["samples", "bands", "ibands"])
+def test_eight_ranks_gloo_fixed_image_all_plans(tmp_path, shard):
+    """world_size 8 (the node BASELINE configs 4 and 5 are quoted on), a fixed 16-spp image (bench.py --total-steps), two lanes per rank.
+    Band plans: a pixel has ONE non-zero addend in the reduction (the other seven ranks add exact zeros), so the reduced accumulator is
+    bit-identical to the bands rendered one after another, whatever order the collective sums in.  Sample plan: eight non-zero addends
+    per pixel; a ring or tree all-reduce adds them in another order than rank order and float addition is not associative, so the
+    statement is a bound, not equality: |reduced - exact| <= 7 * 2^-24 * sum |addend| per component (7 roundings of at most half an ulp
+    of a partial sum each) - about 4e-7 relative, far inside the 1e-4 of the north star."""
+    from magr_ray_tracer_amd import scenes
+    from oracle.oracle_py import Oracle, seed_stream
+    world, lanes, total = 8, 2, 16
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8 % dict(root=ROOT))
+    out = tmp_path / "acc8.npy"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29578", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", "29578", str(script), shard, str(lanes), str(total), str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
+    got = np.load(out)
+    W, H = 40, 24
+    s, view = scenes.cube_scene()
+    sa = s.arrays()
+    cam = scenes.camera_for(view, W, H)
+    o = Oracle(sa, W, H)
+    parts = []
+    for r in range(world):
+        part = np.zeros((H, W, 4), np.float32)
+        mine = rdist.rank_frames(total, r, world) if shard == "samples" else total
+        for m, frames in enumerate(rdist.lane_frames(mine, lanes)):
+            for p in rdist.plans(shard, W, H, r, world, m, lanes, band_rows=2 if shard == "ibands" else None):
+                if frames:
+                    o.render(cam, frames, accum=part, seeds=seed_stream(p["seed_first"], p["seed_count"]), y0=p["y0"], y1=p["y1"])
+        parts.append(part)
+    if shard == "samples":
+        exact = np.sum([p.astype(np.float64) for p in parts], axis=0)
+        bound = 7 * 2.0 ** -24 * np.sum([np.abs(p).astype(np.float64) for p in parts], axis=0)
+        assert (np.abs(got.astype(np.float64) - exact) <= bound + 1e-300).all()
+        assert got[..., :3].sum() > 0 and all(p.any() for p in parts)       # every rank contributed samples
+    else:
+        seq = np.zeros((H, W, 4), np.float32)
+        for p in parts:
+            seq = seq + p
+        assert np.array_equal(got, seq)                                      # bit for bit, independent of the reduction order
+        rows = [y for r in range(world) for p in rdist.plans(shard, W, H, r, world, band_rows=2 if shard == "ibands" else None) for y in range(p["y0"], p["y1"])]
+        assert sorted(rows) == list(range(H))                                # the ranks' bands tile the frame exactly once
+
+
 def test_lanes_are_virtual_ranks_of_the_sample_plan():
     """Lanes partition the samples once more inside a rank: (rank, lane) takes the seed slice of virtual rank rank*lanes + lane, the slices
     of all (rank, lane) pairs tile the stream without gap or overlap, and `steps` frames are shared out exactly."""

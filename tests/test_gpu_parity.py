@@ -585,6 +585,62 @@ def test_persistent_wavefronts_vs_oracle(accel, monkeypatch):
     assert bits_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][3], out[1][3])
 
 
+@pytest.mark.parametrize("stack", ["lds", "spill"])
+def test_persistent_wavefronts_through_a_tlas_vs_oracle(stack, monkeypatch):
+    """k_trace_persist_tlas (BASELINE config 5's kernel: persistent wavefronts through a multi-BLAS TLAS, TLAS entries on the BLAS stack
+    column, the ray transformed once on entering an instance and fetched back from the queue on leaving it).  One workgroup per CU
+    brings its long-queue threshold down to 65,536 rays, so a 640x360 frame runs bounces >= 1 and connect through the event loop and
+    the later bounces through its per-lane branch.  Two scenes: two SBVH BLAS (glass sphere in one), and three BLAS of which one
+    carries a real inverse transform.  Accumulator, RNG state, every work counter (TLAS visits and instance visits included) and the
+    per-pixel `steps` must equal the oracle's, and the one-ray-per-lane nested loops' (extend_variant 4)."""
+    monkeypatch.setenv("RT355_TUNE", "64,20,6,8,1")
+    # "spill": the instantiation for deep trees (config 5's SBVH has 63 levels) - LDS column capped, deeper stack entries in a global
+    # per-lane column; a cap of 6 entries makes nearly every ray of these scenes use the global part.  "lds": the whole column in LDS.
+    monkeypatch.setenv("RT355_SPILL_CAP" if stack == "spill" else "RT355_NO_SPILL", "6" if stack == "spill" else "1")
+    Wd, Hd = 640, 360
+    from magr_ray_tracer_amd.scenes import Scene, _std_materials, box_tris, param_surface
+
+    def three_blas():
+        s = Scene()
+        _std_materials(s)
+        s.AddTriangles(param_surface(lambda U, V: (-2.2 + 1.4 * U, 0.2 + 0.5 * np.sin(6 * U) * np.sin(5 * V) + 0.6, -0.7 + 1.4 * V), 40, 40), "red")
+        s.AddQuad((-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6), "grey")
+        s.AddQuad((-1, 4, -1), (1, 4, -1), (1, 4, 1), (-1, 4, 1), "white-light")
+        s.BuildBLAS(0, 0.0)
+        st = s.num_prims
+        s.AddTriangles(box_tris((0.5, 0.2, -0.7), (1.9, 1.8, 0.7)), "mirror")
+        s.BuildBLAS(st, 1.0)
+        st = s.num_prims
+        s.AddTriangles(box_tris((-0.4, 0, 1.4), (0.4, 0.8, 2.2)), "sand")
+        s.BuildBLAS(st, 1.0)
+        a = np.deg2rad(17.0)
+        s.SetInstanceTransform(1, np.array([[np.cos(a), 0, np.sin(a), 0.13], [0, 1, 0, -0.07], [-np.sin(a), 0, np.cos(a), 0.05], [0, 0, 0, 1]], np.float32))
+        return s, dict(origin=(0.4, 2.2, 5.5), forward=(0.05, 0.2, 0.97), fov=65.0, aperture=0.02)
+
+    for name, fn in (("two SBVH BLAS", lambda: scenes.two_blas_scene(0.0, 48)), ("three BLAS, one rotated", three_blas)):
+        s, view = fn()
+        sa = s.arrays()
+        cam = scenes.camera_for(view, Wd, Hd)
+        o = Oracle(sa, Wd, Hd, **DEFAULT)
+        ref, seeds, e, c = o.render(cam, 2)
+        out = []
+        for variant in (0, 4):
+            d = Device(Wd, Hd, extend_variant=variant, **DEFAULT)
+            d.upload(sa)
+            assert d.kernel_info()["persist"] == ((3 if stack == "spill" else 2) if variant == 0 else 0), name
+            d.seed_default()
+            d.enable_steps(True)
+            d.render(cam, 2)
+            out.append((d.read_accum(), d.get_seeds(), d.counters(), d.get_steps()))
+            d.close()
+        assert_bits(out[0][0], ref, f"persistent wavefronts through the TLAS vs oracle ({name})")
+        assert np.array_equal(out[0][1], seeds)
+        _ctr_equal(out[0][2], e, c)
+        assert out[0][2]["extend_tlas_visits"] > 0 and out[0][2]["extend_rays"] > 2 * 65536
+        assert bits_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][3], out[1][3]), name
+        assert out[0][2] == out[1][2], name      # every counter, connect's own node / triangle counts included: same any-hit order in both kernels
+
+
 def _render_crc(args):
     """Child process: render `frames` frames of the 1280x720 sponza-class scene and return a checksum of accumulator and RNG state."""
     frames, env = args

@@ -14,6 +14,9 @@ from magr_ray_tracer_amd.renderer import Device  # noqa: E402
 from oracle.oracle_py import seed_stream  # noqa: E402
 
 
+LIB = None      # "refb": the build with the reference's OpenCL builtin sequences (librt355_refb.so)
+
+
 def run(case, y):
     fn, vo, _, vi = T.FRAME_VARIANTS[case]
     v = dict(T.DEFAULT, **vi)
@@ -24,7 +27,7 @@ def run(case, y):
     cam["focalLength"] = ref.focus(T.RW // 2, y, cam)
     r = ref.frame_s1(cam, y, y + 1, shading=v["shading"], russian_roulette=v["russian_roulette"])
     ref.close()
-    d = Device(T.RW, T.RH, y0=y, y1=y + 1, **v)
+    d = Device(T.RW, T.RH, y0=y, y1=y + 1, lib=LIB, **v)
     d.upload(sa)
     d.set_seeds(seed_stream(y * T.RW, T.RW))
     d.render(cam, 1)
@@ -37,11 +40,17 @@ def run(case, y):
 
 
 if __name__ == "__main__":
+    if "--refb" in sys.argv:
+        sys.argv.remove("--refb")
+        LIB = "refb"
+        print("library: librt355_refb.so (-DRT355_REF_BUILTINS)")
     for case in (sys.argv[1:] or ["nee", "kajiya_hemi_norr", "fisheye", "nee_bvh4"]):
         good = []
         for y in range(352, 368):
             c_ok, s_ok, mx, bad, counts, rc = run(case, y)
             print(case, y, "counts", c_ok, "seeds", s_ok, "accum max rel", mx, "pixels > 1e-4:", bad, flush=True)
+            if not c_ok:
+                print("   queue lengths HIP", counts, "reference", rc, flush=True)
             if c_ok and s_ok:
                 good.append(y)
         print(f'S1FREE "{case}": {good}', flush=True)

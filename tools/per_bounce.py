@@ -14,8 +14,8 @@ for r in rows:
         frames.append(cur)
     if cur is None:
         continue
-    for key, pat in (("extend", ("k_extend", "k_trace_persist<false", "k_trace_persist4<false", "k_trace_mixed")), ("shade", ("k_shade",)),
-                     ("connect", ("k_connect", "k_trace_persist<true", "k_trace_persist4<true")), ("accumulate", ("k_accumulate",)),
+    for key, pat in (("extend", ("k_extend", "k_trace_persist<false", "k_trace_persist4<false", "k_trace_persist_tlas<false", "k_trace_mixed")), ("shade", ("k_shade",)),
+                     ("connect", ("k_connect", "k_trace_persist<true", "k_trace_persist4<true", "k_trace_persist_tlas<true")), ("accumulate", ("k_accumulate",)),
                      ("generate", ("k_generate",))):
         if any(p in n for p in pat):
             cur[key].append(d)
