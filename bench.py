@@ -350,6 +350,11 @@ def main():
                                 "note": "SURVEY 8(d): R*48 + V_int*96 (+ TLAS / instance terms; BVH4: V4*160) + T_prim*52 from the device work counters, over the same "
                                         "launch time: a throughput, NOT a fraction of HBM peak - the records are re-fetched from the vector L1s and L2s "
                                         "(levels.*), so it may exceed the HBM peak"},
+                # lane utilisation of the event loop's two code paths (device counters): the share of a wave's 64 lanes that had an event of
+                # the kind when that path was issued
+                "lane_utilisation": {"node_path": round(dctr["extend_loop_node_events"] / max(64 * dctr["extend_node_issues"], 1), 3),
+                                     "triangle_path": round(dctr["extend_loop_leaf_events"] / max(64 * dctr["extend_leaf_issues"], 1), 3),
+                                     "node_issues_share": round(dctr["extend_node_issues"] / max(dctr["extend_node_issues"] + dctr["extend_leaf_issues"], 1), 3)},
                 "per_ray": {"node_visits": round(dctr["extend_node_visits"] / max(dctr["extend_rays"], 1), 2),
                             "prim_tests": round(dctr["extend_prim_tests"] / max(dctr["extend_rays"], 1), 2),
                             "tlas_visits": round(dctr["extend_tlas_visits"] / max(dctr["extend_rays"], 1), 3)},

@@ -36,7 +36,8 @@ ShadowRecord = np.dtype([("o", "<f4", 3), ("tmax", "<f4"), ("l", "<f4", 3), ("pi
 Counters = np.dtype([(n, "<u8") for n in (
     "extend_rays", "extend_tlas_visits", "extend_inst_visits", "extend_node_visits", "extend_prim_tests",
     "connect_rays", "connect_tlas_visits", "connect_inst_visits", "connect_node_visits", "connect_prim_tests",
-    "primary_rays", "shadow_rays", "frames", "extend_node_issues", "extend_leaf_issues", "connect_node_issues", "connect_leaf_issues")])
+    "primary_rays", "shadow_rays", "frames", "extend_node_issues", "extend_leaf_issues", "connect_node_issues", "connect_leaf_issues",
+    "extend_loop_node_events", "extend_loop_leaf_events", "connect_loop_node_events", "connect_loop_leaf_events")])
 StageTimes = np.dtype([(n, "<f8") for n in ("generate_ms", "extend_ms", "shade_ms", "compact_ms", "connect_ms", "accumulate_ms")] +
                       [(n, "<i8") for n in ("generate_launches", "extend_launches", "shade_launches", "compact_launches",
                                             "connect_launches", "accumulate_launches")])

@@ -55,7 +55,10 @@ def build_device_refb(force=False):
             os.path.join(ROOT, "include", "rt355_types.h")]
     out = os.path.join(PKG, "librt355_refb.so")
     if force or _stale(out, deps):
-        _run([HIPCC] + DEVICE_FLAGS + ["-DRT355_REF_BUILTINS", src, "-o", out])
+        # -Bsymbolic: this library defines the same global symbols as librt355.so (C-ABI entry points, the kernels' host stubs).  Loaded
+        # into a process that already holds librt355.so, its own references would otherwise bind to THAT library's definitions - and
+        # launch the other build's kernels
+        _run([HIPCC] + DEVICE_FLAGS + ["-DRT355_REF_BUILTINS", "-Wl,-Bsymbolic", src, "-o", out])
     return out
 
 

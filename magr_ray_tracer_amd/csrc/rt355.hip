@@ -394,7 +394,7 @@ static int validate_scene(int accel, const RtPrimitive* prims, int32_t nPrims, c
         for (int32_t i = 0; i < nNodes; i++) for (int k = 0; k < 4; k++) if (n4[i].first[k] != RT_INVALID && n4[i].count[k] > 0 &&
             (int64_t)n4[i].first[k] + n4[i].count[k] > (int64_t)nIdx) return fail(RT_E_INVALID, "bvh4 node %d: leaf range exceeds primIdx", i);
     }
-    if (stackEntriesOut) *stackEntriesOut = std::min(stackCap, std::max(stackNeed + 1, 6)); // >= 6: flush_counters reuses 28 words of it
+    if (stackEntriesOut) *stackEntriesOut = std::min(stackCap, std::max(stackNeed + 1, 6)); // >= 6: flush_counters reuses 36 words of it
     if (texPadOut) *texPadOut = texPad;
     if (tlasDepthOut) *tlasDepthOut = tlasDepth;
     return RT_OK;
@@ -682,7 +682,13 @@ static int configure_traversal(RtCtx* ctx)
             if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l, 0, 0 };
         }
     }
-    if (ctx->persistTlas) {   // RT355_TLAS_FLAT="e,c": extend / connect of multi-BLAS scenes through the one-ray-per-lane branch of k_trace_persist_tlas (A/B runs)
+    if (ctx->persistTlas) {
+        // Multi-BLAS scenes so far are open scenes whose rays take a dozen events (config 5: 1 TLAS visit, 1.5 instance entries, 7.7 box
+        // pairs, 1.9 triangles per ray): extend runs the kernel's one-ray-per-lane branch over every queue (measured per bounce at 4K:
+        // 522 / 446 / 198 us against 654 / 562 / 194 through the event loop and 730 / 643 / 237 through the nested loops at two
+        // workgroups per CU), connect - unoccluded shadow rays cross the whole scene - the event loop (646 against 690 / 1,418 us).
+        // RT355_TLAS_FLAT="e,c" overrides (A/B runs).  profiles/r03_config5_per_bounce.txt
+        ctx->tune.flat = 1; ctx->tuneConnect.flat = 0;
         if (const char* t = getenv("RT355_TLAS_FLAT")) { int a = 0, b = 0; if (sscanf(t, "%d,%d", &a, &b) == 2) { ctx->tune.flat = a; ctx->tuneConnect.flat = b; } }
     }
     ctx->q.spill = nullptr; ctx->q.spillStride = 0; ctx->q.stackCap = 0;
@@ -1018,6 +1024,7 @@ extern "C" int rt_read_counters(RtCtx* ctx, RtCounters* out)
     out->connect_rays = c[0]; out->connect_tlas_visits = c[1]; out->connect_inst_visits = c[2]; out->connect_node_visits = c[3]; out->connect_prim_tests = c[4];
     out->primary_rays = ctx->primaryRays; out->shadow_rays = c[0]; out->frames = ctx->frames;
     out->extend_node_issues = e[5]; out->extend_leaf_issues = e[6]; out->connect_node_issues = c[5]; out->connect_leaf_issues = c[6];
+    out->extend_loop_node_events = e[7]; out->extend_loop_leaf_events = e[8]; out->connect_loop_node_events = c[7]; out->connect_loop_leaf_events = c[8];
     return RT_OK;
 }
 extern "C" int rt_reset_counters(RtCtx* ctx)

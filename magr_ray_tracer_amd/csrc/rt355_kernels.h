@@ -301,8 +301,8 @@ struct TRay {
     float ox, oy, oz, dx, dy, dz, rx, ry, rz;
     float t; int prim; float u, v;
 };
-struct WorkCtr { uint32_t tlas, inst, node, prim, nodeIss = 0, leafIss = 0; };   // nodeIss / leafIss: wave-level issues of the node path / the triangle path by the event loops (x 64 lanes = the slots those events had)
-static constexpr int kCtrCols = 7;
+struct WorkCtr { uint32_t tlas, inst, node, prim, nodeIss = 0, leafIss = 0, evNode = 0, evPrim = 0; };   // nodeIss / leafIss: wave-level issues of the node path / the triangle path by the event loops (x 64 lanes = the slots those events had); evNode / evPrim: the events they carried
+static constexpr int kCtrCols = 9;
 
 RT_FORCEINLINE float slab(const TRay& r, float4 bmin, float4 bmax) // bvh.cl:3-12
 {
@@ -718,7 +718,7 @@ RT_FORCEINLINE int traverse_tlas(const DevScene& sc, TRay& r, uint32_t* stk, Wor
 // per-block partial table (no atomics: one row per blockIdx, launches are stream-ordered).
 RT_FORCEINLINE void flush_counters(unsigned long long* table, uint32_t rays, const WorkCtr& wc, uint32_t* red /* >= kCtrCols*4 words LDS */)
 {
-    uint32_t v[kCtrCols] = { rays, wc.tlas, wc.inst, wc.node, wc.prim, wc.nodeIss, wc.leafIss };
+    uint32_t v[kCtrCols] = { rays, wc.tlas, wc.inst, wc.node, wc.prim, wc.nodeIss, wc.leafIss, wc.evNode, wc.evPrim };
 #pragma unroll
     for (int k = 0; k < kCtrCols; k++)
 #pragma unroll
@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
 #ifdef RT355_TAIL_PROBE
     TAIL_PROBE_EXIT()
 #endif
-    if (lane == 0) { rays = wRays; wc.inst = wRays; wc.node = wNode; wc.prim = wPrim; wc.nodeIss = wNodeIss; wc.leafIss = wLeafIss; }   // the wave's totals enter the reduction once
+    if (lane == 0) { rays = wRays; wc.inst = wRays; wc.node = wNode; wc.prim = wPrim; wc.nodeIss = wNodeIss; wc.leafIss = wLeafIss; wc.evNode = wNode; wc.evPrim = wPrim; }   // the wave's totals enter the reduction once
     flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
 }
 
@@ -1315,7 +1315,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist_tlas(DevScene sc, DevQ
     }
     WorkCtr wc = { 0, 0, 0, 0 };
     uint32_t rays = 0;
-    if (lane == 0) { rays = wRays; wc.tlas = wTlas; wc.inst = wInst; wc.node = wNode; wc.prim = wPrim; wc.nodeIss = wNodeIss; wc.leafIss = wLeafIss; }
+    if (lane == 0) { rays = wRays; wc.tlas = wTlas; wc.inst = wInst; wc.node = wNode; wc.prim = wPrim; wc.nodeIss = wNodeIss; wc.leafIss = wLeafIss; wc.evNode = wNode + wTlas; wc.evPrim = wPrim; }
     flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
 }
 

@@ -585,8 +585,8 @@ def test_persistent_wavefronts_vs_oracle(accel, monkeypatch):
     assert bits_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][3], out[1][3])
 
 
-@pytest.mark.parametrize("stack", ["lds", "spill"])
-def test_persistent_wavefronts_through_a_tlas_vs_oracle(stack, monkeypatch):
+@pytest.mark.parametrize("stack,flat", [("lds", "0,0"), ("spill", "0,0"), ("spill", "1,0"), ("lds", "1,1")])
+def test_persistent_wavefronts_through_a_tlas_vs_oracle(stack, flat, monkeypatch):
     """k_trace_persist_tlas (BASELINE config 5's kernel: persistent wavefronts through a multi-BLAS TLAS, TLAS entries on the BLAS stack
     column, the ray transformed once on entering an instance and fetched back from the queue on leaving it).  One workgroup per CU
     brings its long-queue threshold down to 65,536 rays, so a 640x360 frame runs bounces >= 1 and connect through the event loop and
@@ -597,6 +597,9 @@ def test_persistent_wavefronts_through_a_tlas_vs_oracle(stack, monkeypatch):
     # "spill": the instantiation for deep trees (config 5's SBVH has 63 levels) - LDS column capped, deeper stack entries in a global
     # per-lane column; a cap of 6 entries makes nearly every ray of these scenes use the global part.  "lds": the whole column in LDS.
     monkeypatch.setenv("RT355_SPILL_CAP" if stack == "spill" else "RT355_NO_SPILL", "6" if stack == "spill" else "1")
+    # "e,c": extend / connect through the kernel's event loop (0) or its one-ray-per-lane branch striding over the queue (1; the library's
+    # default for multi-BLAS scenes is 1,0)
+    monkeypatch.setenv("RT355_TLAS_FLAT", flat)
     Wd, Hd = 640, 360
     from magr_ray_tracer_amd.scenes import Scene, _std_materials, box_tris, param_surface
 
@@ -638,7 +641,10 @@ def test_persistent_wavefronts_through_a_tlas_vs_oracle(stack, monkeypatch):
         _ctr_equal(out[0][2], e, c)
         assert out[0][2]["extend_tlas_visits"] > 0 and out[0][2]["extend_rays"] > 2 * 65536
         assert bits_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][3], out[1][3]), name
-        assert out[0][2] == out[1][2], name      # every counter, connect's own node / triangle counts included: same any-hit order in both kernels
+        work = lambda c: {k: v for k, v in c.items() if "issues" not in k and "loop" not in k}
+        assert work(out[0][2]) == work(out[1][2]), name      # every work counter, connect's own node / triangle counts included: same any-hit order in both kernels
+        if flat == "0,0":
+            assert out[0][2]["extend_node_issues"] > 0 and out[0][2]["connect_leaf_issues"] > 0      # the event loops really ran
 
 
 def _render_crc(args):
@@ -899,6 +905,81 @@ def test_lanes_interleaved_sample_streams_match_oracle():
     assert not bits_equal(single, total) and abs(float(single[..., :3].sum()) / float(total[..., :3].sum()) - 1) < 0.05
     one.close()
     g.close()
+
+
+# ---- round 3: lanes behind one handle (rt_group_*) ----------------------------------------------------------------------------------
+def test_group_of_lanes_matches_oracle_sample_streams_and_a_single_lane_is_the_plain_renderer():
+    """rt_group_* (include/rt355.h): one accumulation as `lanes` interleaved sample streams behind ONE handle - own context, stream and
+    seed slice per lane, one device copy of the scene, frames dealt round-robin, accumulator = the lanes added up in lane order on the
+    device.  Three lanes, seven frames (3 + 2 + 2): every lane's accumulator and the group's sum equal the oracle rendering the same seed
+    slices, bit for bit; post-processing works on the summed accumulator with the group's frame count; a group of ONE lane is the plain
+    single-context renderer bit for bit; the streams of the group were measured to run concurrently."""
+    from magr_ray_tracer_amd import dist as rdist
+    from magr_ray_tracer_amd.renderer import Group
+    Wd, Hd, frames, lanes, first = 160, 90, 7, 3, 2
+    s, view = scenes.sponza_class(0.2)
+    sa = s.arrays()
+    cam = scenes.camera_for(view, Wd, Hd)
+    g = Group(Wd, Hd, lanes=lanes, **DEFAULT)
+    g.upload(sa)
+    assert g.concurrency() == lanes and len(g) == lanes
+    g.seed(first)                                     # lane m renders sample stream first + m
+    cam["focalLength"] = g.focus(Wd // 2, Hd // 2, cam)
+    g.render(cam, 4)
+    g.render(cam, 3)                                  # the round-robin continues where the first call stopped
+    total = g.read_accum()
+    assert g.frames() == frames
+    o = Oracle(sa, Wd, Hd, **DEFAULT)
+    exp = None
+    for m, n in enumerate(rdist.lane_frames(frames, lanes)):
+        acc, _, _, _ = o.render(cam, n, seeds=seed_stream((first + m) * Wd * Hd, Wd * Hd))
+        assert_bits(g.devs[m].read_accum(), acc, f"lane {m}")
+        exp = acc if exp is None else exp + acc
+    assert_bits(total, exp, "group accumulator = lanes added in lane order")
+    img, rgba = g.postproc()
+    from oracle.oracle_py import postproc as orc_postproc
+    ref_img, _ = orc_postproc(exp, frames, 0.0, 0.9, 0.0)
+    assert np.abs(img[..., :3] - ref_img[..., :3]).max() < 3e-6 and rgba.shape == (Hd, Wd, 4)
+    g.reset()
+    assert g.frames() == 0 and not g.read_accum().any()
+    g.close()
+    one = Group(Wd, Hd, lanes=1, **DEFAULT)
+    one.upload(sa)
+    one.seed(0)
+    one.render(cam, 3)
+    d = Device(Wd, Hd, **DEFAULT)
+    d.upload(sa)
+    d.seed_default()
+    d.render(cam, 3)
+    assert_bits(one.read_accum(), d.read_accum(), "a group of one lane vs the plain context")
+    assert one.devs[0].kernel_info() == d.kernel_info()       # same kernels, same grids: nothing of the sharing footprint
+    one.close()
+    d.close()
+
+
+def test_renderer_mirror_with_lanes_ticks_whole_rounds():
+    """The C++ Renderer mirror with `lanes` = 2 (host/renderer.cpp): a Tick() adds two frames - one per lane - to ONE accumulation,
+    settings->frames counts them, and the accumulator it reads back is the sum of the two sample streams as the oracle renders them."""
+    from magr_ray_tracer_amd.renderer import Renderer
+    Wd, Hd = 160, 90
+    s, view = scenes.cube_scene()
+    sa = s.arrays()
+    r = Renderer(s, Wd, Hd)
+    r.SetLanes(2)
+    r.SetCamera(view["origin"], view["forward"], view["fov"], view["aperture"])
+    r.Init()
+    r.Tick(3)
+    assert r.frames() == 1 + 3 * 2
+    got, energy = r.read()
+    cam = r.camera()
+    o = Oracle(sa, Wd, Hd, **DEFAULT)
+    exp = None
+    for m in range(2):
+        acc, _, _, _ = o.render(cam, 3, seeds=seed_stream(m * Wd * Hd, Wd * Hd))
+        exp = acc if exp is None else exp + acc
+    assert_bits(got, exp, "Renderer with two lanes")
+    assert energy > 0
+    r.close()
 
 
 # ---- round 2 -----------------------------------------------------------------------------------------------------------------

@@ -494,6 +494,37 @@ def test_tlas_refuses_more_than_256_instances():
         s.arrays(bvh4=False)
 
 
+def test_upload_validation_without_a_gpu_refuses_oversized_and_malformed_tlas():
+    """rt_validate_scene = the host-side checks rt_upload_scene runs before it touches the device.  TLAS child ids and instance ids
+    travel as 15-bit values on the traversal stacks (bit 15 = leaf), so a caller-provided TLAS with more than 32768 nodes or instances
+    would pop the wrong node: refused with RT_E_UNSUPPORTED.  Also: the same call accepts a scene the repo's own builders made, and
+    refuses a TLAS cycle and an out-of-range child."""
+    lib = W.device_lib()
+    s, _ = scenes.two_blas_scene(0.0, 8)
+    sa = s.arrays()
+
+    def validate(tlas, blas, accel=0):
+        nodes = sa.nodes(accel)
+        P = W.ptr
+        return lib.rt_validate_scene(accel, P(sa.prims), len(sa.prims), P(sa.mats), len(sa.mats), None, 0, P(sa.lights), len(sa.lights),
+                                     P(nodes), len(nodes), P(sa.primIdx), len(sa.primIdx), P(tlas), len(tlas), P(blas), len(blas))
+    assert validate(sa.tlas, sa.blas) == 0 and validate(sa.tlas, sa.blas, 1) == 0
+    # 32769 instances of BLAS 0 under a right-leaning chain of TLAS nodes would need 16-bit ids: refused before anything else is looked at
+    big_blas = np.repeat(sa.blas[:1], 0x8001)
+    rc = validate(sa.tlas, big_blas)
+    assert rc == -4 and b"32768" in lib.rt_last_error()
+    big_tlas = np.zeros(0x8001, dtype=sa.tlas.dtype)
+    rc = validate(big_tlas, sa.blas)
+    assert rc == -4 and b"32768" in lib.rt_last_error()
+    cyc = sa.tlas.copy()
+    inner = 0                                                   # node 0 is the root the kernels start from (tlas.cpp:38)
+    cyc["leftRight"][inner] = (inner << 16) | (int(cyc["leftRight"][inner]) & 0xffff)      # right child = itself
+    assert validate(cyc, sa.blas) == -1 and b"twice" in lib.rt_last_error()
+    bad = sa.tlas.copy()
+    bad["leftRight"][inner] = (len(bad) << 16) | 1
+    assert validate(bad, sa.blas) == -1 and b"out of range" in lib.rt_last_error()
+
+
 def test_bvh4_collapse_of_the_reference_13_node_fixture():
     """The one builder fixture the reference holds: the hand-built 13-node BVH2 of src/bvh.cpp:615-674 (disabled `#if 0` debugging
     input of BVH4::BVH4, no expected output recorded).  The collapse BVH4::Convert / Collapse (bvh.cpp:695-787) prescribes for it,
