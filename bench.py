@@ -158,11 +158,17 @@ def main():
         raise SystemExit("--same-device puts every rank on GPU 0, which RCCL refuses: use --backend gloo")
 
     import numpy as np
-    # librt355.so first: when it is loaded it asks HIP for eight hardware queues (lanes whose streams share a queue are serialised),
-    # which only works before HIP initialises - i.e. before the first torch.cuda call
+    # Load order decides which HIP runtime the process runs on: torch first = the ROCm 7.0 runtime bundled in the torch wheel, librt355.so
+    # first = the system's ROCm 7.2 (the library's RUNPATH).  A single context is 12 % faster on the former (732 against 645 M samples/s,
+    # EXPERIMENTS.md (44)); RT355_IMPORT_ORDER=lib-first selects the latter for A/B runs.  Either way librt355.so is loaded before HIP
+    # INITIALISES (importing torch does not initialise it), which is when its request for eight hardware queues has to be in place.
     from magr_ray_tracer_amd import _lib
+    if os.environ.get("RT355_IMPORT_ORDER") != "lib-first":
+        import torch
     _lib.device_lib()
     import torch
+    if os.environ.get("RT355_IMPORT_ORDER"):
+        print("libamdhip64 in use:", sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln}), file=sys.stderr)
     from magr_ray_tracer_amd import dist as rdist, scenes
     from magr_ray_tracer_amd.renderer import Device, Group
 
@@ -346,6 +352,12 @@ def main():
                 "frac": lv[bound]["frac"] if bound else None,
                 "traffic": lv["hbm"]["bytes"] if "hbm" in lv else None,
                 "traffic_source": (tr1 or {}).get("source", "no committed PMC measurement matches this configuration (profiles/r03_traffic.json)"),
+                # what bounds the kernel when no memory level is near its peak: a dependent chain of record fetches per ray (PMC, same passes)
+                "limiter": dict({"what": "latency of a dependent fetch chain x lane divergence, not bandwidth at any level: waves of the extend launches are "
+                                         "parked in s_waitcnt for `wait_any` of their lifetime, `valu_lane_utilisation` of the lanes of an issued vector "
+                                         "instruction hold a ray in that state, the vector L1s are busy (any request in flight) for `vl1d_busy` of the launch"},
+                                **({"wait_any": tr1["extend_wave_time"]["wait_any"], "valu_lane_utilisation": tr1["extend_wave_time"]["valu_lane_utilisation"],
+                                    "vl1d_busy": tr1.get("extend_vl1d_busy")} if tr1 and tr1.get("extend_wave_time") else {})),
                 "algorithmic": {"bytes_per_launch": int(alg), "gbs": round(alg / e_s / 1e9, 1),
                                 "note": "SURVEY 8(d): R*48 + V_int*96 (+ TLAS / instance terms; BVH4: V4*160) + T_prim*52 from the device work counters, over the same "
                                         "launch time: a throughput, NOT a fraction of HBM peak - the records are re-fetched from the vector L1s and L2s "

@@ -600,7 +600,7 @@ def test_persistent_wavefronts_through_a_tlas_vs_oracle(stack, flat, monkeypatch
     # "e,c": extend / connect through the kernel's event loop (0) or its one-ray-per-lane branch striding over the queue (1; the library's
     # default for multi-BLAS scenes is 1,0)
     monkeypatch.setenv("RT355_TLAS_FLAT", flat)
-    Wd, Hd = 640, 360
+    Wd, Hd = 960, 540          # bounce 1 still holds more than 65,536 rays
     from magr_ray_tracer_amd.scenes import Scene, _std_materials, box_tris, param_surface
 
     def three_blas():
