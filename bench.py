@@ -84,6 +84,7 @@ def parse_args():
     ap.add_argument("--extend-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stage launches with HIP events")
+    ap.add_argument("--profile-lanes", action="store_true", help="bracket the extend launches of the first lane in the timed region too (diagnostic: lane0_launch_ms_while_sharing)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="nccl = RCCL over xGMI (default); gloo only for rehearsals")
     ap.add_argument("--same-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses GPU 0 (requires --backend gloo)")
     ap.add_argument("--no-single", action="store_true", help="skip the untimed single-context pass (profiler runs: only the timed workload's launches)")
@@ -201,12 +202,14 @@ def main():
     cam = scenes.camera_for(view, W, H)
     reduced = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}")
 
-    # one group (= `lanes` sample streams behind one handle) per row band this rank owns; HIP events bracket the extend launches of the
-    # first group's first lane only (hundreds of launches of the roofline's kernel are timed either way)
+    # one group (= `lanes` sample streams behind one handle) per row band this rank owns.  The timed region runs WITHOUT HIP-event brackets
+    # when lanes share the GPU (they cost 1.2 % of the frame rate and time nothing usable: a lane's launch takes longer while other lanes'
+    # kernels run beside it); --profile-lanes brackets the extend launches of the first lane for that diagnostic.  The roofline's kernel
+    # time comes from the single-context pass below.
     made = []
     for p in rdist.plans(args.shard, W, H, rank, world, 0, lanes, args.band_rows or None):
         g = Group(W, H, lanes=lanes, y0=p["y0"], y1=p["y1"], accel=accel, shading=shading, device=local,
-                  profile=0 if args.no_profile or made else 1, extend_variant=args.extend_variant, persist_blocks_per_cu=args.persist_blocks)
+                  profile=1 if args.profile_lanes and not args.no_profile and not made else 0, extend_variant=args.extend_variant, persist_blocks_per_cu=args.persist_blocks)
         if made:
             g.share_scene(made[0])          # one device copy of the scene for all contexts of this rank
         else:
@@ -321,6 +324,15 @@ def main():
             st2, c1 = solo.stage_times(), solo.counters()
             stage_tab = {k[:-3]: round(st2[k] / 16, 4) for k in st2 if k.endswith("_ms") and k != "compact_ms"}
             dctr = {k: c1[k] - c0[k] for k in c1}
+            # lane utilisation of the event loop's two paths: counted by the instantiation that also records per-ray `steps` (4 more frames)
+            solo.enable_steps(True)
+            solo.render(cam, 4)
+            solo.synchronize()
+            c2 = solo.counters()
+            solo.enable_steps(False)
+            for k in c2:
+                if "issues" in k or "loop" in k:
+                    dctr[k] = c2[k] - c1[k]
         kernel_name = solo.extend_kernel_name()
         solo.close()
         barrier()

@@ -72,7 +72,9 @@ typedef struct RtCounters {
     uint64_t frames;
     /* how often the persistent event loops issued their two code paths (wave level) and how many events those issues carried:
      * loop_node_events / (64 * node_issues) is the share of the lanes that had a box pair to test when the node path ran,
-     * loop_leaf_events / (64 * leaf_issues) the same for the triangle path (launches that ran one ray per lane count nothing here) */
+     * loop_leaf_events / (64 * leaf_issues) the same for the triangle path.  Counted by the extend instantiation that also keeps the
+     * per-ray `steps` (rt_debug_enable_steps(ctx, 1) or renderBVH): the production kernel does not pay for them; launches that ran one
+     * ray per lane count nothing here */
     uint64_t extend_node_issues, extend_leaf_issues, connect_node_issues, connect_leaf_issues;
     uint64_t extend_loop_node_events, extend_loop_leaf_events, connect_loop_node_events, connect_loop_leaf_events;   /* the events those issues carried */
 } RtCounters;

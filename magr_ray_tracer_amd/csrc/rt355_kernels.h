@@ -964,9 +964,11 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
             if ((lm | im) == 0ull) break;
             const bool doLeaf = im == 0ull || __popcll(lm) >= kLeafK;
             bool done = false, occluded = false;
-            if (!doLeaf) { wNode += (uint32_t)__popcll(im); wNodeIss++; }
+            // (the path-issue counters behind RtCounters.*_issues live in the STEPS instantiation only: two scalar adds per iteration cost the
+            // production kernel 2-4 % on bounces 1-3)
+            if (!doLeaf) { wNode += (uint32_t)__popcll(im); if (STEPS) wNodeIss++; }
             if (doLeaf) {
-                wPrim += (uint32_t)__popcll(lm); wLeafIss++;
+                wPrim += (uint32_t)__popcll(lm); if (STEPS) wLeafIss++;
                 if (atLeaf) {
                     const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
                     test_tri_packed(sc, first, r);
@@ -1017,7 +1019,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
 #ifdef RT355_TAIL_PROBE
     TAIL_PROBE_EXIT()
 #endif
-    if (lane == 0) { rays = wRays; wc.inst = wRays; wc.node = wNode; wc.prim = wPrim; wc.nodeIss = wNodeIss; wc.leafIss = wLeafIss; wc.evNode = wNode; wc.evPrim = wPrim; }   // the wave's totals enter the reduction once
+    if (lane == 0) { rays = wRays; wc.inst = wRays; wc.node = wNode; wc.prim = wPrim; if (STEPS) { wc.nodeIss = wNodeIss; wc.leafIss = wLeafIss; wc.evNode = wNode; wc.evPrim = wPrim; } }   // the wave's totals enter the reduction once
     flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
 }
 
@@ -1251,7 +1253,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist_tlas(DevScene sc, DevQ
             const bool doLeaf = im == 0ull || __popcll(lm) >= kLeafK;
             bool done = false, occluded = false, needPop = false;
             if (doLeaf) {
-                wPrim += (uint32_t)__popcll(lm); wLeafIss++;
+                wPrim += (uint32_t)__popcll(lm); if (STEPS) wLeafIss++;
                 if (atLeaf) {
                     const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
                     test_tri_packed(sc, first, r);
@@ -1260,7 +1262,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist_tlas(DevScene sc, DevQ
                     else needPop = true;
                 }
             } else {
-                wNodeIss++;
+                if (STEPS) wNodeIss++;
                 const bool isT = (cur & kTagTlas) != 0u;
                 const unsigned long long tm = __ballot(atNode && isT);
                 wTlas += (uint32_t)__popcll(tm); wNode += (uint32_t)(__popcll(im) - __popcll(tm));
@@ -1315,7 +1317,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist_tlas(DevScene sc, DevQ
     }
     WorkCtr wc = { 0, 0, 0, 0 };
     uint32_t rays = 0;
-    if (lane == 0) { rays = wRays; wc.tlas = wTlas; wc.inst = wInst; wc.node = wNode; wc.prim = wPrim; wc.nodeIss = wNodeIss; wc.leafIss = wLeafIss; wc.evNode = wNode + wTlas; wc.evPrim = wPrim; }
+    if (lane == 0) { rays = wRays; wc.tlas = wTlas; wc.inst = wInst; wc.node = wNode; wc.prim = wPrim; if (STEPS) { wc.nodeIss = wNodeIss; wc.leafIss = wLeafIss; wc.evNode = wNode + wTlas; wc.evPrim = wPrim; } }
     flush_counters(OCC ? q.ctrConnect : q.ctrExtend, rays, wc, stk);
 }
 

@@ -644,7 +644,7 @@ def test_persistent_wavefronts_through_a_tlas_vs_oracle(stack, flat, monkeypatch
         work = lambda c: {k: v for k, v in c.items() if "issues" not in k and "loop" not in k}
         assert work(out[0][2]) == work(out[1][2]), name      # every work counter, connect's own node / triangle counts included: same any-hit order in both kernels
         if flat == "0,0":
-            assert out[0][2]["extend_node_issues"] > 0 and out[0][2]["connect_leaf_issues"] > 0      # the event loops really ran
+            assert out[0][2]["extend_node_issues"] > 0 and out[0][2]["extend_loop_leaf_events"] > 0      # the event loop really ran (its path-issue counters are kept by the `steps` instantiation, which this test switches on)
 
 
 def _render_crc(args):
@@ -1026,6 +1026,51 @@ def test_bench_starts_its_own_ranks_two_on_one_gpu(tmp_path):
     # a failing rank must surface as a non-zero exit code of the launcher
     bad = subprocess.run(cmd[:-2] + ["--shard", "nonsense"], env=env, capture_output=True, text=True, timeout=300, cwd=root)
     assert bad.returncode != 0
+
+
+def test_bench_fixed_image_split_over_two_ranks_with_lanes_inside_bands(tmp_path):
+    """`bench.py --total-steps T` renders a FIXED T-spp image split over the ranks ("scaling": "strong"; the north star's 256 / 1024 spp
+    over 8 GPUs) - here config 4's plan in miniature: two ranks (rehearsal form: same device, gloo), the frame cut into row bands dealt
+    round-robin (ibands), TWO lanes per band (sample streams 0 and 1 of those rows, rt_group handles), 5 spp in all.  The reduced
+    accumulator equals the oracle rendering every (band, lane) with its seed slice and frame share, bit for bit: a pixel has one non-zero
+    addend across ranks, and a band's lanes are added in lane order."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from magr_ray_tracer_amd import dist as rdist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    Wd, Hd, total, lanes, rows = 320, 180, 5, 2, 23
+    dump = tmp_path / "acc.npy"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--total-steps", str(total),
+           "--shard", "ibands", "--band-rows", str(rows), "--lanes", str(lanes), "--warmup", "0", "--no-cpu-baseline", "--no-repeat",
+           "--width", str(Wd), "--height", str(Hd), "--detail", "0.2", "--dump-accum", str(dump)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == total and line["config"]["lanes"] == lanes
+    assert line["value"] > 0 and abs(line["value"] - Wd * Hd * total / (line["ms_per_step"] * total * 1e-3) / 1e6) < 1e-2 * line["value"]
+    got = np.load(dump)
+    s, view = scenes.sponza_class(0.2)
+    sa = s.arrays(bvh4=False)
+    cam = scenes.camera_for(view, Wd, Hd)
+    d = Device(Wd, Hd, y0=0, y1=rows, **DEFAULT)             # bench focuses through rank 0's first context (band 0)
+    d.upload(sa)
+    cam["focalLength"] = d.focus(Wd // 2, Hd // 2, cam)
+    d.close()
+    o = Oracle(sa, Wd, Hd, **DEFAULT)
+    exp = np.zeros((Hd, Wd, 4), np.float32)
+    for rank in range(2):
+        for p0 in rdist.plans("ibands", Wd, Hd, rank, 2, band_rows=rows):
+            band = None
+            for m, frames in enumerate(rdist.lane_frames(total, lanes)):      # [3, 2]
+                p = rdist.plans("ibands", Wd, Hd, rank, 2, m, lanes, band_rows=rows)[[q["y0"] for q in rdist.plans("ibands", Wd, Hd, rank, 2, band_rows=rows)].index(p0["y0"])]
+                acc = np.zeros((Hd, Wd, 4), np.float32)
+                o.render(cam, frames, accum=acc, seeds=seed_stream(p["seed_first"], p["seed_count"]), y0=p["y0"], y1=p["y1"])
+                band = acc if band is None else band + acc
+            exp = exp + band
+    assert_bits(got, exp, "fixed 5-spp image, two ranks x interleaved bands x two lanes")
 
 
 def test_bench_scene_1080p_band_vs_oracle_counters_equal():

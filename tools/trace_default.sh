@@ -7,4 +7,4 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT"
 grep '^{' "$OUT/bench.log" | tail -1 > "$OUT/bench.json"
 f=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
 head -8 "$f" | cut -d, -f1-4 | cut -c1-150
-python3 -c "import json; d=json.loads(open('$OUT/bench.json').read()); print('bench value', d['value'], 'extend avg_launch_ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'])"
+python3 -c "import json; d=json.loads(open('$OUT/bench.json').read()); print('bench value', d['value'], 'ms_per_step', d['ms_per_step'])"
