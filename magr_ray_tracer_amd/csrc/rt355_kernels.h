@@ -1072,7 +1072,7 @@ template <bool SPILL> RT_FORCEINLINE uint32_t stk_pop(const uint32_t* stk, const
     return (!SPILL || sp < q.stackCap) ? stk[sp * kBlock + threadIdx.x] : q.spill[(size_t)(sp - q.stackCap) * q.spillStride + gl];
 }
 template <bool OCC, bool STEPS = false, bool SPILL = false>
-__global__ __launch_bounds__(kBlock) void k_trace_persist_tlas(DevScene sc, DevQueues q, int b0, int b1, int renderBVH, PersistTune tune)
+__global__ __launch_bounds__(kBlock, 7) void k_trace_persist_tlas(DevScene sc, DevQueues q, int b0, int b1, int renderBVH, PersistTune tune)
 {
     const int kChunk = tune.chunk, kRefill = tune.refill, kInner = tune.inner, kLeafK = tune.leafK;
     extern __shared__ uint32_t stk[];
