@@ -647,6 +647,58 @@ def test_persistent_wavefronts_through_a_tlas_vs_oracle(stack, flat, monkeypatch
             assert out[0][2]["extend_node_issues"] > 0 and out[0][2]["extend_loop_leaf_events"] > 0      # the event loop really ran (its path-issue counters are kept by the `steps` instantiation, which this test switches on)
 
 
+def test_persistent_wavefronts_through_a_deeper_tlas_many_instances(monkeypatch):
+    """Twelve BLAS on a ring under one TLAS (agglomerative clustering, tlas.cpp:8-52: several TLAS levels, so pending TLAS siblings
+    really sit on the tagged stack column between two instance visits, and a ray enters several instances one after the other), two of
+    them with a real inverse transform.  k_trace_persist_tlas (event loop for extend and connect, one workgroup per CU so that every
+    bounce of the 960x540 frame with more than 65,536 rays runs it) against the oracle - accumulator, RNG state, every work counter -
+    and against the nested loops."""
+    monkeypatch.setenv("RT355_TUNE", "64,20,6,8,1")
+    monkeypatch.setenv("RT355_TLAS_FLAT", "0,0")
+    Wd, Hd = 960, 540
+    from magr_ray_tracer_amd.scenes import Scene, _std_materials, box_tris, param_surface
+    s = Scene()
+    _std_materials(s)
+    s.AddQuad((-9, 0, -9), (-9, 0, 9), (9, 0, 9), (9, 0, -9), "grey")
+    s.AddQuad((-1.5, 6, -1.5), (1.5, 6, -1.5), (1.5, 6, 1.5), (-1.5, 6, 1.5), "white-light")
+    s.BuildBLAS(0, 1.0)
+    mats = ["red", "green", "sand", "mirror", "white"]
+    for k in range(11):
+        st = s.num_prims
+        a = 2 * np.pi * k / 11
+        cx, cz = 3.2 * np.cos(a), 3.2 * np.sin(a)
+        if k % 3 == 0:
+            s.AddTriangles(param_surface(lambda U, V, cx=cx, cz=cz: (cx - 0.6 + 1.2 * U, 0.3 + 0.9 * V + 0.25 * np.sin(5 * U + k), cz + 0.3 * np.cos(4 * V)), 12, 12), mats[k % 5])
+        else:
+            s.AddTriangles(box_tris((cx - 0.45, 0.0, cz - 0.45), (cx + 0.45, 0.6 + 0.15 * k, cz + 0.45)), mats[k % 5])
+        s.BuildBLAS(st, 1.0 if k % 2 else 0.0)
+    for b, ang in ((3, 11.0), (8, -23.0)):
+        a = np.deg2rad(ang)
+        s.SetInstanceTransform(b, np.array([[np.cos(a), 0, np.sin(a), 0.07], [0, 1, 0, -0.03], [-np.sin(a), 0, np.cos(a), 0.04], [0, 0, 0, 1]], np.float32))
+    sa = s.arrays()
+    assert len(sa.blas) == 12 and len(sa.tlas) >= 23
+    cam = scenes.camera_for(dict(origin=(0.5, 4.2, 8.5), forward=(0.03, 0.42, 0.9), fov=70.0, aperture=0.02), Wd, Hd)
+    o = Oracle(sa, Wd, Hd, **DEFAULT)
+    ref, seeds, e, c = o.render(cam, 2)
+    assert e["tlas_visits"] > 1.5 * e["rays"] and e["inst_visits"] > e["rays"]      # several TLAS levels (depth 5) and more than one instance per ray on average
+    out = []
+    for variant in (0, 4):
+        d = Device(Wd, Hd, extend_variant=variant, **DEFAULT)
+        d.upload(sa)
+        assert d.kernel_info()["persist"] == (2 if variant == 0 else 0)
+        d.seed_default()
+        d.enable_steps(True)
+        d.render(cam, 2)
+        out.append((d.read_accum(), d.get_seeds(), d.counters(), d.get_steps()))
+        d.close()
+    assert_bits(out[0][0], ref, "twelve BLAS under a TLAS: persistent wavefronts vs oracle")
+    assert np.array_equal(out[0][1], seeds)
+    _ctr_equal(out[0][2], e, c)
+    assert out[0][2]["extend_node_issues"] > 0
+    work = lambda cc: {k: v for k, v in cc.items() if "issues" not in k and "loop" not in k}
+    assert bits_equal(out[0][0], out[1][0]) and np.array_equal(out[0][3], out[1][3]) and work(out[0][2]) == work(out[1][2])
+
+
 def _render_crc(args):
     """Child process: render `frames` frames of the 1280x720 sponza-class scene and return a checksum of accumulator and RNG state."""
     frames, env = args
