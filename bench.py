@@ -357,7 +357,8 @@ def main():
                 lv, bound = level_table(tr1["extend_bytes_per_launch"], e_s)
             roof.update({
                 "timed": "ONE context with the GPU to itself: the %d extend launches of 16 frames, kernel-attached HIP events (hipExtLaunchKernelGGL); "
-                         "7 x avg_launch_ms <= the single-context frame time by construction" % e_launches,
+                         "7 x avg_launch_ms <= the single-context frame time by construction; rocprofv3 --kernel-trace --stats of the same context: "
+                         "profiles/r03_kernel_stats_lanes1.csv ((6 x k_trace_persist<false, false, false> + k_trace_persist<false, true, false>) / 7)" % e_launches,
                 "avg_launch_ms": round(e_s * 1e3, 5), "launches": e_launches,
                 "levels": lv, "bound": bound,
                 "achieved": lv[bound]["gbs"] if bound else None, "peak": lv[bound]["peak"] if bound else None,
