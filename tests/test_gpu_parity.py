@@ -884,6 +884,77 @@ def test_fuzz_random_triangle_soups(seed, big=False):
     d.close()
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_random_multi_blas_soups(seed, monkeypatch, big=False):
+    """Random triangle soups cut into 2-6 BLAS (each its own BuildBLAS with its own SBVH alpha) under a TLAS, some instances with a
+    random rigid inverse transform, random camera / kernel variant / frame size, and a random way through k_trace_persist_tlas: LDS
+    stack or a stack capped at 6-8 entries with the global spill, extend and connect through the event loop or the one-ray-per-lane
+    branch (one workgroup per CU, so queues above 65,536 rays take the long-queue code).  Accumulator, RNG state and every work counter
+    (TLAS and instance visits included) bit-exact against the oracle."""
+    from magr_ray_tracer_amd.scene import Scene, material
+    rng = np.random.default_rng(7000 + seed)
+    monkeypatch.setenv("RT355_TUNE", "64,20,6,8,1")
+    monkeypatch.setenv("RT355_TLAS_FLAT", str(rng.choice(["0,0", "1,0", "1,1", "0,1"])))
+    cap = int(rng.choice([0, 6, 8]))
+    if cap:
+        monkeypatch.setenv("RT355_SPILL_CAP", str(cap))
+    else:
+        monkeypatch.setenv("RT355_NO_SPILL", "1")
+    s = Scene()
+    s.AddMaterial("a", material(color=rng.random(3)))
+    s.AddMaterial("b", material(color=rng.random(3)))
+    s.AddMaterial("m", material(color=rng.random(3), specular=float(rng.choice([0.3, 0.9, 1.0]))))
+    s.AddMaterial("g", material(color=(1, 1, 1), dielectric=True, n1=1.0, n2=1.3, specular=0.05, absorption=(0.02, 0.05, 0.01)))
+    s.AddMaterial("l1", material(color=(1, 1, 1), light=True, emittance=tuple(rng.random(3) * 40 + 5)))
+    nb = int(rng.integers(2, 7))
+    # BLAS 0: floor + ceiling light (so that every ray has something to hit and NEE has a light)
+    s.AddTriangles(np.array([[[-9, -4.5, -9], [9, -4.5, 9], [9, -4.5, -9]], [[-9, -4.5, -9], [-9, -4.5, 9], [9, -4.5, 9]]], np.float32), "a")
+    s.AddTriangles(np.array([[[-6, 7, -6], [6, 7, -6], [6, 7, 6]], [[6, 7, 6], [-6, 7, 6], [-6, 7, -6]]], np.float32), "l1", flipNormal=True)
+    s.BuildBLAS(0, alpha=1.0)
+    for b in range(1, nb):
+        st = s.num_prims
+        n = int(rng.integers(20, 160))
+        centre = rng.random(3) * 6 - 3
+        c = centre + (rng.random((n, 1, 3)) - 0.5) * 3.0
+        size = np.where(rng.random((n, 1, 1)) < 0.15, 2.0, 0.5)
+        tris = (c + (rng.random((n, 3, 3)) - 0.5) * size).astype(np.float32)
+        if n > 30:
+            tris[20:24] = tris[16:20]                                     # exact duplicates (ties)
+        names = rng.choice(["a", "b", "m", "g"], size=n, p=[0.4, 0.3, 0.2, 0.1])
+        for k in ("a", "b", "m", "g"):
+            sel = tris[names == k]
+            if len(sel):
+                s.AddTriangles(sel, k)
+        s.BuildBLAS(st, alpha=float(rng.choice([1.0, 1e-5, 0.0])))
+        if rng.random() < 0.5:                                            # a rigid world -> instance transform (rotation about y + a small shift)
+            a = float(rng.random() * 0.8 - 0.4)
+            t = (rng.random(3) - 0.5) * 0.6
+            s.SetInstanceTransform(b, np.array([[np.cos(a), 0, np.sin(a), t[0]], [0, 1, 0, t[1]], [-np.sin(a), 0, np.cos(a), t[2]], [0, 0, 0, 1]], np.float32))
+    sa = s.arrays()
+    assert len(sa.blas) == nb
+    Wd, Hd = int(rng.integers(17, 200)), int(rng.integers(9, 120))
+    if big or seed % 4 == 0:        # every fourth seed (and tools/deep_fuzz.py multi big): queues long enough for the event loop and the refill machinery
+        Wd, Hd = int(rng.integers(300, 420)), int(rng.integers(200, 260))
+    v = dict(DEFAULT, accel=int(rng.random() < 0.2), shading=int(rng.integers(0, 2)), sampling=int(rng.integers(0, 2)),
+             russian_roulette=bool(rng.integers(0, 2)), filter_fireflies=bool(rng.integers(0, 2)))
+    org = rng.random(3) * 6 - 3 + np.array([0, 0, 9.0])
+    cam = scenes.make_camera(Wd, Hd, tuple(org), tuple(np.array([0.0, 0.1, 1.0]) + (rng.random(3) - 0.5) * 0.4), fov=float(rng.integers(40, 120)),
+                             aperture=float(rng.choice([0.0, 0.1])))
+    o = Oracle(sa, Wd, Hd, **v)
+    d = Device(Wd, Hd, **v)
+    d.upload(sa)
+    if v["accel"] == 0:
+        assert d.kernel_info()["persist"] in (2, 3)
+    frames = 3
+    acc, seeds, e, c = o.render(cam, frames)
+    d.seed_default()
+    d.render(cam, frames)
+    assert_bits(d.read_accum(), acc, f"seed {seed}: {nb} BLAS {Wd}x{Hd} {v} cap {cap}")
+    assert np.array_equal(d.get_seeds(), seeds)
+    _ctr_equal(d.counters(), e, c)
+    d.close()
+
+
 def test_textured_plane_and_stray_texture_indices():
     """A textured plane seen on both sides of its origin (negative u and v: the reference's lookup then lands up to a whole texture past
     the texture's window, primitives.cl:137-146) with the texture LAST in the atlas, and a triangle whose uv reach exactly 1: HIP and
