@@ -108,7 +108,9 @@ static size_t stack_bytes(const RtCtx* c) { return (size_t)c->stackEntries * kBl
 // k_trace_persist_tlas keeps its pending TLAS siblings (<= one per level) on the same column; with spillStack only the first kSpillCap
 // entries of a column live in LDS
 static int tlas_stack_entries(const RtCtx* c) { return c->stackEntries + c->tlasDepth + 1; }
-static size_t tlas_stack_bytes(const RtCtx* c) { return (size_t)(c->spillStack ? c->spillCap : tlas_stack_entries(c)) * kBlock * sizeof(uint32_t); }
+static constexpr int kBackupWords = 10;   // the world ray (O, D, 1/D) + the TLAS level's pruning distance, kept in LDS across an instance visit (PersistTune.backup)
+static int tlas_lds_entries(const RtCtx* c) { return c->spillStack ? c->spillCap : tlas_stack_entries(c); }
+static size_t tlas_stack_bytes(const RtCtx* c) { return (size_t)(tlas_lds_entries(c) + (c->tune.backup ? kBackupWords : 0)) * kBlock * sizeof(uint32_t); }
 
 // ---- profiling brackets --------------------------------------------------------------
 // Stage timing: a fixed ring of HIP event pairs on the context's stream.  Recording never forces a device sync: when the ring
@@ -643,10 +645,15 @@ static int configure_traversal(RtCtx* ctx)
                        ctx->tlasDepth <= 8 && ctx->nInterior < (1 << 29);
     // deep trees (an SBVH at alpha = 0: config 5's second BLAS has 63 levels): a full LDS column per lane would leave two workgroups per
     // CU, so the column is capped and its deep end spills to global memory (rt355_kernels.h, stk_push / stk_pop)
-    ctx->spillCap = kSpillCap;
+    // the world ray of a lane waits in LDS while the lane is inside an instance (10 words per lane) instead of being fetched back from the
+    // queue on the way out: one global round trip less per instance visit (config 5: 1.5 visits among a ray's dozen events).  The stack
+    // column's LDS share shrinks accordingly (12 + 10 words per lane keep seven workgroups per CU).  RT355_TLAS_BACKUP=0 switches it off.
+    const bool backup = !(getenv("RT355_TLAS_BACKUP") && atoi(getenv("RT355_TLAS_BACKUP")) == 0);
+    ctx->tune.backup = ctx->tuneConnect.backup = ctx->persistTlas && backup ? 1 : 0;   // (the LDS size of the occupancy query below depends on it)
+    ctx->spillCap = backup ? kSpillCap - kBackupWords + 2 : kSpillCap;
     bool forceSpill = false;
     if (const char* t = getenv("RT355_SPILL_CAP")) { const int v = atoi(t); if (v >= 6 && v <= 64) { ctx->spillCap = v; forceSpill = true; } }
-    ctx->spillStack = ctx->persistTlas && (tlas_stack_entries(ctx) > kFitSeven || forceSpill) && tlas_stack_entries(ctx) > ctx->spillCap &&
+    ctx->spillStack = ctx->persistTlas && (tlas_stack_entries(ctx) + (backup ? kBackupWords : 0) > kFitSeven || forceSpill) && tlas_stack_entries(ctx) > ctx->spillCap &&
                       !(getenv("RT355_NO_SPILL") && atoi(getenv("RT355_NO_SPILL")));
     if (ctx->persistTlas && !ctx->spillStack && tlas_stack_entries(ctx) > RT_BVH4_STACK + 9) ctx->persistTlas = false;
     if (ctx->persist || ctx->persist4 || ctx->persistTlas) {
@@ -682,6 +689,7 @@ static int configure_traversal(RtCtx* ctx)
             if (sscanf(t, "%d,%d,%d,%d", &a, &b, &c, &l) == 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tuneConnect = PersistTune{ a, b, c, l, 0, 0 };
         }
     }
+    ctx->tune.backup = ctx->tuneConnect.backup = 0;
     if (ctx->persistTlas) {
         // Multi-BLAS scenes so far are open scenes whose rays take a dozen events (config 5: 1 TLAS visit, 1.5 instance entries, 7.7 box
         // pairs, 1.9 triangles per ray): extend runs the kernel's one-ray-per-lane branch over every queue (measured per bounce at 4K:
@@ -689,9 +697,11 @@ static int configure_traversal(RtCtx* ctx)
         // workgroups per CU), connect - unoccluded shadow rays cross the whole scene - the event loop (646 against 690 / 1,418 us).
         // RT355_TLAS_FLAT="e,c" overrides (A/B runs).  profiles/r03_config5_per_bounce.txt
         ctx->tune.flat = 1; ctx->tuneConnect.flat = 0;
+        ctx->tune.backup = ctx->tuneConnect.backup = backup ? 1 : 0;   // (set here, after RT355_TUNE has been parsed: that assignment resets the struct)
         if (const char* t = getenv("RT355_TLAS_FLAT")) { int a = 0, b = 0; if (sscanf(t, "%d,%d", &a, &b) == 2) { ctx->tune.flat = a; ctx->tuneConnect.flat = b; } }
     }
     ctx->q.spill = nullptr; ctx->q.spillStride = 0; ctx->q.stackCap = 0;
+    ctx->q.tlasLdsEntries = ctx->persistTlas ? (uint32_t)tlas_lds_entries(ctx) : 0u;
     if (ctx->spillStack) {   // every SPILL launch runs on a persistent grid (bounce 0 too), so the global columns are bounded by the grids
         const size_t stride = (size_t)std::max(ctx->persistGrid, ctx->persistGridConnect) * kBlock;
         const size_t words = stride * (size_t)(tlas_stack_entries(ctx) - ctx->spillCap);

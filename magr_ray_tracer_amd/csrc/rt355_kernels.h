@@ -83,6 +83,7 @@ struct DevQueues {
     unsigned long long* ctrConnect; // [gridMax][kCtrCols]
     uint32_t* spill;   // [spillEntries][spillStride] deep ends of the traversal stacks (SPILL instantiations), may be null
     uint32_t spillStride, stackCap;   // lanes of the largest SPILL launch; LDS entries per lane of those launches
+    uint32_t tlasLdsEntries;          // LDS stack entries per lane of k_trace_persist_tlas (the world-ray backup, if any, sits behind them)
     int32_t nPix, firstPixel, width, height;
 };
 // k_shade hands its tiles out by ticket.  ONE counter: any running workgroup draws the smallest tile not drawn yet, so the ordered scan
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int
 static constexpr int kTpWaves = 8192;
 __device__ unsigned long long g_tp[9][kTpWaves][4];
 #endif
-struct PersistTune { int chunk, refill, inner, leafK, fixedChunks, flat = 0; };   // flat: k_trace_persist_tlas runs every queue through its one-ray-per-lane branch, 64 rays per wave and round (short traversals: config 5's open scene)   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path, chunks dealt round-robin instead of dequeued
+struct PersistTune { int chunk, refill, inner, leafK, fixedChunks, flat = 0, backup = 0; };   // backup: k_trace_persist_tlas keeps the world ray in LDS across an instance visit (10 words per lane behind the stack column) instead of fetching it back from the queue   // flat: k_trace_persist_tlas runs every queue through its one-ray-per-lane branch, 64 rays per wave and round (short traversals: config 5's open scene)   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path, chunks dealt round-robin instead of dequeued
 
 // Short queue (late bounces, and bounce 0 when it is launched with one workgroup per 256 rays): every wave gets at most one 64-ray chunk
 // and nothing is left to refill from, so run the plain one-ray-per-lane loop, which has less per-step overhead than the refill machine.
@@ -1126,6 +1127,12 @@ __global__ __launch_bounds__(kBlock, 7) void k_trace_persist_tlas(DevScene sc, D
                     r.dx = dot3(mk4(t0.x, t0.y, t0.z, 0), Dv); r.dy = dot3(mk4(t1.x, t1.y, t1.z, 0), Dv); r.dz = dot3(mk4(t2.x, t2.y, t2.z, 0), Dv);
                     r.ox = dot3(mk4(t0.x, t0.y, t0.z, 0), Ov) + t0.w; r.oy = dot3(mk4(t1.x, t1.y, t1.z, 0), Ov) + t1.w;
                     r.oz = dot3(mk4(t2.x, t2.y, t2.z, 0), Ov) + t2.w;
+                    if (tune.backup) {   // the world ray waits in LDS (the reference keeps a 128-byte copy of the Ray, tlas.cl:12,21-23)
+                        uint32_t* bk = stk + q.tlasLdsEntries * kBlock + threadIdx.x;
+                        bk[0] = __float_as_uint(Ov.x); bk[kBlock] = __float_as_uint(Ov.y); bk[2 * kBlock] = __float_as_uint(Ov.z);
+                        bk[3 * kBlock] = __float_as_uint(Dv.x); bk[4 * kBlock] = __float_as_uint(Dv.y); bk[5 * kBlock] = __float_as_uint(Dv.z);
+                        bk[6 * kBlock] = __float_as_uint(r.rx); bk[7 * kBlock] = __float_as_uint(r.ry); bk[8 * kBlock] = __float_as_uint(r.rz);
+                    }
                     r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
                     wc.inst++;
                     cur = __float_as_uint(t3.x);
@@ -1158,11 +1165,19 @@ __global__ __launch_bounds__(kBlock, 7) void k_trace_persist_tlas(DevScene sc, D
                 }
                 if (needPop) {
                     if (inInst && sp == spBase) {
-                        float4 O, D;
-                        if (OCC) { const float4 a = q.sA[qFirst + idx], b = q.sB[qFirst + idx]; O = a; D = b; tLight = a.w; }
-                        else { O = q.O[b0 & 1][idx]; D = q.D[b0 & 1][idx]; tLight = kFar; }
-                        r.ox = O.x; r.oy = O.y; r.oz = O.z; r.dx = D.x; r.dy = D.y; r.dz = D.z;
-                        r.rx = 1.0f / D.x; r.ry = 1.0f / D.y; r.rz = 1.0f / D.z;
+                        if (tune.backup) {
+                            const uint32_t* bk = stk + q.tlasLdsEntries * kBlock + threadIdx.x;
+                            r.ox = __uint_as_float(bk[0]); r.oy = __uint_as_float(bk[kBlock]); r.oz = __uint_as_float(bk[2 * kBlock]);
+                            r.dx = __uint_as_float(bk[3 * kBlock]); r.dy = __uint_as_float(bk[4 * kBlock]); r.dz = __uint_as_float(bk[5 * kBlock]);
+                            r.rx = __uint_as_float(bk[6 * kBlock]); r.ry = __uint_as_float(bk[7 * kBlock]); r.rz = __uint_as_float(bk[8 * kBlock]);
+                            tLight = tmax;
+                        } else {
+                            float4 O, D;
+                            if (OCC) { const float4 a = q.sA[qFirst + idx], b = q.sB[qFirst + idx]; O = a; D = b; tLight = a.w; }
+                            else { O = q.O[b0 & 1][idx]; D = q.D[b0 & 1][idx]; tLight = kFar; }
+                            r.ox = O.x; r.oy = O.y; r.oz = O.z; r.dx = D.x; r.dy = D.y; r.dz = D.z;
+                            r.rx = 1.0f / D.x; r.ry = 1.0f / D.y; r.rz = 1.0f / D.z;
+                        }
                         inInst = false; spBase = 0;
                     }
                     if (sp == 0) break;
@@ -1244,6 +1259,13 @@ __global__ __launch_bounds__(kBlock, 7) void k_trace_persist_tlas(DevScene sc, D
                     r.dx = dot3(mk4(t0.x, t0.y, t0.z, 0), Dv); r.dy = dot3(mk4(t1.x, t1.y, t1.z, 0), Dv); r.dz = dot3(mk4(t2.x, t2.y, t2.z, 0), Dv);
                     r.ox = dot3(mk4(t0.x, t0.y, t0.z, 0), Ov) + t0.w; r.oy = dot3(mk4(t1.x, t1.y, t1.z, 0), Ov) + t1.w;
                     r.oz = dot3(mk4(t2.x, t2.y, t2.z, 0), Ov) + t2.w;
+                    if (tune.backup) {
+                        uint32_t* bk = stk + q.tlasLdsEntries * kBlock + threadIdx.x;
+                        bk[0] = __float_as_uint(Ov.x); bk[kBlock] = __float_as_uint(Ov.y); bk[2 * kBlock] = __float_as_uint(Ov.z);
+                        bk[3 * kBlock] = __float_as_uint(Dv.x); bk[4 * kBlock] = __float_as_uint(Dv.y); bk[5 * kBlock] = __float_as_uint(Dv.z);
+                        bk[6 * kBlock] = __float_as_uint(r.rx); bk[7 * kBlock] = __float_as_uint(r.ry); bk[8 * kBlock] = __float_as_uint(r.rz);
+                        bk[9 * kBlock] = __float_as_uint(tLight);       // the TLAS level's pruning distance (connect: t_light; extend: 1e30)
+                    }
                     r.rx = 1.0f / r.dx; r.ry = 1.0f / r.dy; r.rz = 1.0f / r.dz;
                     cur = __float_as_uint(t3.x);          // encoded BLAS root (interior id or leaf)
                     spBase = sp; inInst = true; tLight = r.t;   // intersectBVH2 prunes against ray.t on entry (bvh.cl:19)
@@ -1295,9 +1317,18 @@ __global__ __launch_bounds__(kBlock, 7) void k_trace_persist_tlas(DevScene sc, D
             }
             if (needPop) {
                 if (inInst && sp == spBase) {   // the instance's tree is exhausted: back to world space (tlas.cl:21-23)
-                    float tmax;
-                    world_ray(slot, tmax);
-                    tLight = tmax; inInst = false; spBase = 0;   // the TLAS level prunes against the ray.t of ITS entry (tlas.cl:31)
+                    if (tune.backup) {
+                        const uint32_t* bk = stk + q.tlasLdsEntries * kBlock + threadIdx.x;
+                        r.ox = __uint_as_float(bk[0]); r.oy = __uint_as_float(bk[kBlock]); r.oz = __uint_as_float(bk[2 * kBlock]);
+                        r.dx = __uint_as_float(bk[3 * kBlock]); r.dy = __uint_as_float(bk[4 * kBlock]); r.dz = __uint_as_float(bk[5 * kBlock]);
+                        r.rx = __uint_as_float(bk[6 * kBlock]); r.ry = __uint_as_float(bk[7 * kBlock]); r.rz = __uint_as_float(bk[8 * kBlock]);
+                        tLight = __uint_as_float(bk[9 * kBlock]);
+                    } else {
+                        float tmax;
+                        world_ray(slot, tmax);
+                        tLight = tmax;
+                    }
+                    inInst = false; spBase = 0;   // the TLAS level prunes against the ray.t of ITS entry (tlas.cl:31)
                 }
                 if (sp == 0) done = true;
                 else cur = stk_pop<SPILL>(stk, q, gl, sp);

@@ -685,7 +685,7 @@ def test_persistent_wavefronts_through_a_deeper_tlas_many_instances(monkeypatch)
     for variant in (0, 4):
         d = Device(Wd, Hd, extend_variant=variant, **DEFAULT)
         d.upload(sa)
-        assert d.kernel_info()["persist"] == (2 if variant == 0 else 0)
+        assert d.kernel_info()["persist"] in ((2, 3) if variant == 0 else (0,))     # (3: stack column capped, its deep end in global memory)
         d.seed_default()
         d.enable_steps(True)
         d.render(cam, 2)
