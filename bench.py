@@ -138,6 +138,17 @@ def load_traffic(match):
     return None
 
 
+PEAK_VALU_GINST = 1024 * 2.4 / 4      # wave64 vector instructions per ns: 256 CUs x 4 SIMDs, one instruction per SIMD every 4 clocks at 2.4 GHz
+
+
+def issue_entry(insts, seconds):
+    """vector-issue roofline: wave-level VALU instructions (PMC: SQ_INSTS_VALU, unit pinned by tools/pmc_calib.hip calib_valu) over a time."""
+    if not insts or seconds <= 0:
+        return None
+    g = insts / seconds / 1e9
+    return {"valu_wave_insts": int(insts), "ginst_per_s": round(g, 1), "peak": PEAK_VALU_GINST, "frac": round(g / PEAK_VALU_GINST, 4)}
+
+
 def level_table(bytes_by_level, seconds):
     """{level: {bytes, gbs, peak, frac}} and the bound (the level with the largest fraction) for `bytes` moved in `seconds`."""
     lv = {}
@@ -371,6 +382,8 @@ def main():
                                          "instruction hold a ray in that state, the vector L1s are busy (any request in flight) for `vl1d_busy` of the launch"},
                                 **({"wait_any": tr1["extend_wave_time"]["wait_any"], "valu_lane_utilisation": tr1["extend_wave_time"]["valu_lane_utilisation"],
                                     "vl1d_busy": tr1.get("extend_vl1d_busy")} if tr1 and tr1.get("extend_wave_time") else {})),
+                # the same launches against the vector ALUs' issue rate (not a memory level: reported beside `levels`, `bound` stays a memory level)
+                "valu_issue": issue_entry((tr1 or {}).get("extend_valu_insts_per_launch"), e_s),
                 "algorithmic": {"bytes_per_launch": int(alg), "gbs": round(alg / e_s / 1e9, 1),
                                 "note": "SURVEY 8(d): R*48 + V_int*96 (+ TLAS / instance terms; BVH4: V4*160) + T_prim*52 from the device work counters, over the same "
                                         "launch time: a throughput, NOT a fraction of HBM peak - the records are re-fetched from the vector L1s and L2s "
@@ -398,6 +411,7 @@ def main():
             jlv, jbound = level_table(trj["frame_bytes"], ms_per_step * 1e-3)
             job.update({"levels": jlv, "bound": jbound, "frac": jlv[jbound]["frac"] if jbound else None, "traffic_source": trj.get("source", ""),
                         "note": "bytes of ALL kernels of a frame (PMC passes of this configuration with %d lane(s)) over ms_per_step" % lanes})
+            job["valu_issue"] = issue_entry(trj.get("frame_valu_insts"), ms_per_step * 1e-3)
         job["algorithmic_gbs"] = round((extend_bytes(ctr, accel) + extend_bytes(ctr, accel, "connect")) / max(frames_mine, 1) / (ms_per_step * 1e-3) / 1e9, 1)
         roof["job"] = job
         if st_lane0["extend_launches"] > 0 and lanes > 1:

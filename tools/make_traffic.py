@@ -18,7 +18,11 @@ What a count is worth, measured by the calibration (1 GiB streamed with 16 B per
                    streams, ~10 % of the requests, move 128 B each, so this is a LOWER estimate by at most that much)
   TCP_TOTAL_CACHE_ACCESSES_sum   64 B per access for the streaming read and store; 1.25 accesses per 16-byte lane-load in the record gather
                    = 12.8 B delivered per access -> vl1d bytes = accesses x 12.8 B (bytes the vector L1 delivered to the lanes)
-Levels and peaks (MI355X_MICROARCH.md): hbm 8 TB/s; l2 34.5 TB/s aggregate; vl1d 64 B per clock and CU (x 256 CUs x 2.4 GHz).
+  SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU   wave-level vector instructions / the quad-cycles (4 clocks) a SIMD's vector ALU was held by them:
+                   calib_valu issues a known number of v_fma_f32 (8 waves per SIMD, nothing else) - both counters must equal it, and its run
+                   time gives the chip's issue peak: one wave64 instruction per SIMD every 4 clocks, 1,024 SIMDs
+Levels and peaks (MI355X_MICROARCH.md): hbm 8 TB/s; l2 34.5 TB/s aggregate; vl1d 64 B per clock and CU (x 256 CUs x 2.4 GHz);
+vector issue 1,024 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instructions/s.
 """
 import csv
 import json
@@ -55,7 +59,8 @@ def calibration():
     if not os.path.exists(path):
         return None
     t = load(path)
-    known = {"calib_stream": 1 << 30, "calib_store": 1 << 30, "calib_gather<4>": 458752 * 64 * 64, "calib_gather<64>": 458752 * 64 * 64}
+    known = {"calib_stream": 1 << 30, "calib_store": 1 << 30, "calib_gather<4>": 458752 * 64 * 64, "calib_gather<64>": 458752 * 64 * 64,
+             "calib_valu": 2048 * 4 * 4096 * 64}   # the last one: wave-level v_fma_f32 instructions, not bytes
     out = {}
     for k, c in t.items():
         name = next((n for n in known if n in k), None)
@@ -63,8 +68,10 @@ def calibration():
             continue
         out[name] = {cn: round(known[name] / (s / d), 2) for cn, (d, s) in c.items() if s > 0 and cn in (
             "FETCH_SIZE", "WRITE_SIZE", "TCC_REQ_sum", "TCC_READ_sum", "TCC_WRITE_sum", "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum",
-            "TCP_TOTAL_CACHE_ACCESSES_sum", "TCC_EA0_RDREQ_DRAM_sum", "TCC_MISS_sum")}
+            "TCP_TOTAL_CACHE_ACCESSES_sum", "TCC_EA0_RDREQ_DRAM_sum", "TCC_MISS_sum") or (name == "calib_valu" and cn in (
+            "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE", "SQ_THREAD_CYCLES_VALU"))}
     return {"known_bytes_per_dispatch": known, "bytes_per_count": out,
+            "note_valu": "calib_valu: known wave-level v_fma_f32 count / counter value; 1.0 for SQ_INSTS_VALU and SQ_ACTIVE_INST_VALU = one quad-cycle per wave64 instruction",
             "note": "FETCH_SIZE / WRITE_SIZE count KB: 2048 for calib_stream = half the bytes reported; 64 B per TCC request and 12.8 B per vector-L1 access in the record gather"}
 
 
@@ -121,6 +128,11 @@ def entry(label, args, cfg):
          "extend_counts_per_launch": {k: round(v / ext_launches, 1) for k, v in sorted(ext.items())}}
     if con_launches:
         e["connect_bytes_per_launch"] = levels(con, con_launches)
+    if "SQ_INSTS_VALU" in ext:     # wave-level vector instructions (x 4 clocks of one SIMD each): the issue roofline
+        e["extend_valu_insts_per_launch"] = int(ext["SQ_INSTS_VALU"] / ext_d["SQ_INSTS_VALU"])
+        e["frame_valu_insts"] = int(allk.get("SQ_INSTS_VALU", 0))
+        if con_launches and "SQ_INSTS_VALU" in con:
+            e["connect_valu_insts_per_launch"] = int(con["SQ_INSTS_VALU"] / con_d["SQ_INSTS_VALU"])
     # what the SIMDs and the vector L1 did meanwhile (fractions of the extend launches' own cycles)
     if "SQ_WAVE_CYCLES" in ext and ext["SQ_WAVE_CYCLES"] > 0:
         e["extend_wave_time"] = {"wait_any": round(ext.get("SQ_WAIT_ANY", 0) / ext["SQ_WAVE_CYCLES"], 3),

@@ -3,6 +3,9 @@
 //   calib_gather  dependent random 64-byte record fetches, 4 x global_load_dwordx4 per lane and record (the traversal's node event),
 //                 from a table that fits the L2s (4 MB) / the Infinity Cache only (64 MB): lanes x steps x 64 B known exactly
 //   calib_store   a coalesced streaming store, 16 B per lane
+//   calib_valu    nothing but vector arithmetic: 4 independent chains of v_fma_f32 per lane, 8 waves per SIMD; the number of wave-level
+//                 vector instructions is known exactly (waves x iterations x 64 + a few) -> the unit of SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU /
+//                 SQ_WAVE_CYCLES (quad-cycles?) and the issue peak of the chip (one wave64 instruction per SIMD every 4 clocks)
 // Run under `rocprofv3 --pmc <set> --kernel-trace` (tools/r3_pmc.sh); tools/make_traffic.py divides the counter values of these three
 // kernels by the byte counts printed here to get bytes-per-count for TCP_TOTAL_CACHE_ACCESSES, TCP_TCC_READ_REQ, TCC_HIT + TCC_MISS,
 // FETCH_SIZE and WRITE_SIZE in THIS access pattern (MI355X_MICROARCH.md, HBM section: "calibrate on a known byte count in your own
@@ -43,6 +46,18 @@ __global__ __launch_bounds__(256) void calib_gather(const float4* __restrict__ t
     out[gid] = acc;
 }
 
+__global__ __launch_bounds__(256) void calib_valu(float* out, int iters, float a, float b)
+{
+    float x0 = threadIdx.x, x1 = x0 + 1.f, x2 = x0 + 2.f, x3 = x0 + 3.f;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            asm volatile("v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a), "v"(b));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3;
+}
+
 int main()
 {
     const size_t streamBytes = (size_t)1 << 30;          // 1 GiB
@@ -73,6 +88,10 @@ int main()
         }
         CHK(hipDeviceSynchronize());
     }
+    const int valuIters = 4096, valuBlocks = 256 * 8;
+    for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(calib_valu, dim3(valuBlocks), dim3(256), 0, 0, out, valuIters, 0.999f, 0.001f);
+    CHK(hipDeviceSynchronize());
+    printf("calib_valu wave_instructions_per_dispatch %zu (waves %d x iterations %d x 64 v_fma_f32; + loop and epilogue)\n", (size_t)valuBlocks * 4 * valuIters * 64, valuBlocks * 4, valuIters);
     printf("calib_stream bytes_per_dispatch %zu\ncalib_store bytes_per_dispatch %zu\ncalib_gather bytes_per_dispatch %zu (lanes %d x steps %d x 64 B; tables 4 MB <4> and 64 MB <64>)\n",
            streamBytes, streamBytes, (size_t)lanes * steps * 64, lanes, steps);
     return 0;

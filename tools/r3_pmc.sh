@@ -14,7 +14,6 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"; do
   i=$((i+1))
   if [ "${1:-}" = "calib" ]; then
-    [ $i -le 2 ] && continue
     timeout -k 10 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/pass$i" -- "$GRAFT_REPO_ROOT/tools/pmc_calib.bin" > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed: $(tail -2 $OUT/pass$i.log)"
   else
     timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/pass$i" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 8 --warmup 1 --no-repeat --no-single --no-cpu-baseline --no-profile "$@" > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed: $(tail -2 $OUT/pass$i.log)"
