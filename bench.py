@@ -138,7 +138,10 @@ def load_traffic(match):
     return None
 
 
-PEAK_VALU_GINST = 1024 * 2.4 / 4      # wave64 vector instructions per ns: 256 CUs x 4 SIMDs, one instruction per SIMD every 4 clocks at 2.4 GHz
+# wave64 vector instructions per ns the chip issues when it does nothing else - MEASURED (tools/pmc_calib.hip calib_valu_mix: the slab test's
+# own op mix, 8 waves per SIMD; profiles/r03_pmc_calibration*.csv): 0.43 per clock and SIMD at the 2.04 GHz it holds under that load.
+# On paper 1,024 SIMDs x 2.4 GHz / 2 clocks = 1,229.
+PEAK_VALU_GINST = 928.0
 
 
 def issue_entry(insts, seconds):
@@ -146,7 +149,8 @@ def issue_entry(insts, seconds):
     if not insts or seconds <= 0:
         return None
     g = insts / seconds / 1e9
-    return {"valu_wave_insts": int(insts), "ginst_per_s": round(g, 1), "peak": PEAK_VALU_GINST, "frac": round(g / PEAK_VALU_GINST, 4)}
+    return {"valu_wave_insts": int(insts), "ginst_per_s": round(g, 1), "peak": PEAK_VALU_GINST, "peak_source": "measured: tools/pmc_calib.hip calib_valu_mix",
+            "frac": round(g / PEAK_VALU_GINST, 4)}
 
 
 def level_table(bytes_by_level, seconds):

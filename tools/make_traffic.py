@@ -18,11 +18,14 @@ What a count is worth, measured by the calibration (1 GiB streamed with 16 B per
                    streams, ~10 % of the requests, move 128 B each, so this is a LOWER estimate by at most that much)
   TCP_TOTAL_CACHE_ACCESSES_sum   64 B per access for the streaming read and store; 1.25 accesses per 16-byte lane-load in the record gather
                    = 12.8 B delivered per access -> vl1d bytes = accesses x 12.8 B (bytes the vector L1 delivered to the lanes)
-  SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU   wave-level vector instructions / the quad-cycles (4 clocks) a SIMD's vector ALU was held by them:
-                   calib_valu issues a known number of v_fma_f32 (8 waves per SIMD, nothing else) - both counters must equal it, and its run
-                   time gives the chip's issue peak: one wave64 instruction per SIMD every 4 clocks, 1,024 SIMDs
+  SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU   wave-level vector instructions: calib_valu issues a known number of v_fma_f32 (8 waves per SIMD, four
+                   independent chains per lane, nothing else), calib_valu_mix the slab test's own mix (sub, mul, min, max, cmp, cndmask, add_u32,
+                   and_b32) - both counters equal the known count to 0.006 %, and the run times (profiles/r03_pmc_calibration_kernel_stats.csv:
+                   2.40 / 2.31 ms for 2,147 M instructions) give the chip's MEASURED vector issue rate: 893 / 928 G wave-instructions/s
+                   = 0.43 per clock and SIMD at the 2.04 GHz the chip holds under that load (a wave64 FP32 instruction takes 2 clocks on
+                   the 32-lane FP32 datapath; 1,024 SIMDs x 2.4 GHz / 2 = 1,229 G/s on paper)
 Levels and peaks (MI355X_MICROARCH.md): hbm 8 TB/s; l2 34.5 TB/s aggregate; vl1d 64 B per clock and CU (x 256 CUs x 2.4 GHz);
-vector issue 1,024 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instructions/s.
+vector issue: the measured 928 G wave-instructions/s.
 """
 import csv
 import json
@@ -60,18 +63,18 @@ def calibration():
         return None
     t = load(path)
     known = {"calib_stream": 1 << 30, "calib_store": 1 << 30, "calib_gather<4>": 458752 * 64 * 64, "calib_gather<64>": 458752 * 64 * 64,
-             "calib_valu": 2048 * 4 * 4096 * 64}   # the last one: wave-level v_fma_f32 instructions, not bytes
+             "calib_valu_mix": 2048 * 4 * 4096 * 64, "calib_valu": 2048 * 4 * 4096 * 64}   # the last two: wave-level vector instructions, not bytes
     out = {}
     for k, c in t.items():
         name = next((n for n in known if n in k), None)
         if not name:
             continue
-        out[name] = {cn: round(known[name] / (s / d), 2) for cn, (d, s) in c.items() if s > 0 and cn in (
+        out[name] = {cn: round(known[name] / (s / d), 2) for cn, (d, s) in c.items() if s > 0 and not name.startswith("calib_valu") and cn in (
             "FETCH_SIZE", "WRITE_SIZE", "TCC_REQ_sum", "TCC_READ_sum", "TCC_WRITE_sum", "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum",
-            "TCP_TOTAL_CACHE_ACCESSES_sum", "TCC_EA0_RDREQ_DRAM_sum", "TCC_MISS_sum") or (name == "calib_valu" and cn in (
+            "TCP_TOTAL_CACHE_ACCESSES_sum", "TCC_EA0_RDREQ_DRAM_sum", "TCC_MISS_sum") or (name.startswith("calib_valu") and cn in (
             "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE", "SQ_THREAD_CYCLES_VALU"))}
     return {"known_bytes_per_dispatch": known, "bytes_per_count": out,
-            "note_valu": "calib_valu: known wave-level v_fma_f32 count / counter value; 1.0 for SQ_INSTS_VALU and SQ_ACTIVE_INST_VALU = one quad-cycle per wave64 instruction",
+            "note_valu": "calib_valu / calib_valu_mix: known wave-level instruction count / counter value: 1.0 for SQ_INSTS_VALU and SQ_ACTIVE_INST_VALU (they count instructions)",
             "note": "FETCH_SIZE / WRITE_SIZE count KB: 2048 for calib_stream = half the bytes reported; 64 B per TCC request and 12.8 B per vector-L1 access in the record gather"}
 
 

@@ -58,6 +58,20 @@ __global__ __launch_bounds__(256) void calib_valu(float* out, int iters, float a
     out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3;
 }
 
+// the slab test's own mix: subtract, multiply, min, max, compare, select - are they all issued at the rate of the fused multiply-add?
+__global__ __launch_bounds__(256) void calib_valu_mix(float* out, int iters, float a, float b)
+{
+    float x0 = threadIdx.x, x1 = x0 + 1.f, x2 = x0 + 2.f, x3 = x0 + 3.f;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            asm volatile("v_sub_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %5\n\tv_min_f32 %2, %2, %0\n\tv_max_f32 %3, %3, %1\n\t"
+                         "v_cmp_lt_f32 vcc, %2, %3\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_add_u32 %2, %2, %3\n\tv_and_b32 %3, %3, %2"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a), "v"(b) : "vcc");
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3;
+}
+
 int main()
 {
     const size_t streamBytes = (size_t)1 << 30;          // 1 GiB
@@ -90,7 +104,9 @@ int main()
     }
     const int valuIters = 4096, valuBlocks = 256 * 8;
     for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(calib_valu, dim3(valuBlocks), dim3(256), 0, 0, out, valuIters, 0.999f, 0.001f);
+    for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(calib_valu_mix, dim3(valuBlocks), dim3(256), 0, 0, out, valuIters, 0.999f, 0.001f);
     CHK(hipDeviceSynchronize());
+    printf("calib_valu_mix wave_instructions_per_dispatch %zu (waves %d x iterations %d x 64: sub, mul, min, max, cmp, cndmask, add_u32, and_b32 in equal parts)\n", (size_t)valuBlocks * 4 * valuIters * 64, valuBlocks * 4, valuIters);
     printf("calib_valu wave_instructions_per_dispatch %zu (waves %d x iterations %d x 64 v_fma_f32; + loop and epilogue)\n", (size_t)valuBlocks * 4 * valuIters * 64, valuBlocks * 4, valuIters);
     printf("calib_stream bytes_per_dispatch %zu\ncalib_store bytes_per_dispatch %zu\ncalib_gather bytes_per_dispatch %zu (lanes %d x steps %d x 64 B; tables 4 MB <4> and 64 MB <64>)\n",
            streamBytes, streamBytes, (size_t)lanes * steps * 64, lanes, steps);
