@@ -42,7 +42,8 @@ RUNS = {
     "config4_lanes1": ("--config 4 --lanes 1", dict(config=4, accel="bvh4", detail=1.0, width=1920, height=1080, model=False, lanes=1)),
     "config4_lanes4": ("--config 4", dict(config=4, accel="bvh4", detail=1.0, width=1920, height=1080, model=False, lanes=4)),
     "config5_lanes1": ("--config 5 --lanes 1", dict(config=5, accel="bvh2", detail=1.0, width=3840, height=2160, model=False, lanes=1)),
-    "config5_lanes4": ("--config 5", dict(config=5, accel="bvh2", detail=1.0, width=3840, height=2160, model=False, lanes=4)),
+    "config5_lanes4": ("--config 5 --lanes 4", dict(config=5, accel="bvh2", detail=1.0, width=3840, height=2160, model=False, lanes=4)),
+    "config5_lanes6": ("--config 5", dict(config=5, accel="bvh2", detail=1.0, width=3840, height=2160, model=False, lanes=6)),
     "config2_lanes1": ("--config 2 --lanes 1", dict(config=2, accel="bvh2", detail=1.0, width=1280, height=720, model=False, lanes=1)),
 }
 EXTEND = ("k_trace_persist<false", "k_trace_persist4<false", "k_trace_persist_tlas<false", "k_extend<")
