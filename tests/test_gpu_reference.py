@@ -180,11 +180,13 @@ def test_whole_frame_free_running_oracle_vs_reference_kernels(case, band):
     print(case, band, stats)
 
 
-@pytest.mark.parametrize("accel", [0, 1])
-def test_extend_every_bounce_hip_vs_reference_kernel_bit_exact(accel):
+@pytest.mark.parametrize("accel,queues", [(0, "short"), (1, "short"), (0, "long"), (1, "long")])
+def test_extend_every_bounce_hip_vs_reference_kernel_bit_exact(accel, queues, monkeypatch):
     """The rays the reference's own frame traced at bounces 0..6 (w-lane-polluted directions, rays inside glass, rays leaving
     mirrors) through the HIP extend: t, primIdx, u, v, I, N bit for bit; and the reference's heat-map values (renderBVH,
-    wavefront.cl:66-67) against the HIP `steps`."""
+    wavefront.cl:66-67) against the HIP `steps`.  "short": the captured queues as they are (the kernels' one-ray-per-lane branch);
+    "long": each queue tiled past 65,536 rays on persistent grids of one workgroup per CU, so that the EVENT LOOPS of k_trace_persist /
+    k_trace_persist4 trace them (the reference's extend is run on the same tiled queue)."""
     v = dict(DEFAULT, accel=accel)
     y0, y1 = 356, 364
     s, view = scenes.branch_scene()
@@ -192,8 +194,16 @@ def test_extend_every_bounce_hip_vs_reference_kernel_bit_exact(accel):
     cam = scenes.camera_for(view, RW, RH)
     ref = ref_gpu.RefGPU(sa, **v)
     cap = ref.frame_s0(cam, y0, y1)
+    if queues == "long":
+        monkeypatch.setenv("RT355_TUNE", "64,20,6,8,1")
+        y0, y1 = 0, RH
+        for b in range(len(cap["ext"])):
+            if len(cap["ext"][b]):
+                cap["ext"][b] = np.tile(cap["ext"][b], -(-70000 // len(cap["ext"][b])))
     d = Device(RW, RH, y0=y0, y1=y1, **v)
     d.upload(sa)
+    if queues == "long":
+        assert d.kernel_info()["persist" if accel == 0 else "persist4"] == 1
     d.enable_steps()
     total = 0
     for b, ext in enumerate(cap["ext"]):
@@ -214,8 +224,71 @@ def test_extend_every_bounce_hip_vs_reference_kernel_bit_exact(accel):
         mine = d.get_steps()[:len(ext)]
         assert_bits(mine.astype(np.float32) / np.float32(255.0), heat[:, 0], f"bounce {b} steps/255")
         assert np.array_equal(np.rint(heat[:, 0].astype(np.float64) * 255).astype(np.int32), mine)
+        if queues == "long":                           # and the instantiation without the `steps` bookkeeping (the one a render runs)
+            d.enable_steps(False)
+            d.set_rays(b, ext)
+            d.stage_extend(b)
+            lean = d.get_rays(b)
+            d.enable_steps(True)
+            for f in ("t", "primIdx", "u", "v", "I", "N"):
+                assert_bits(lean[f], got[f], f"bounce {b} extend {f}: with and without steps")
         total += len(ext)
     assert total > 30000 and sum(int((e["inside"] != 0).sum()) for e in cap["ext"]) > 1000
+    d.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("mode", ["loop", "loop-spill", "flat"])
+def test_extend_every_bounce_tlas_kernel_vs_reference_kernel_bit_exact(mode, monkeypatch):
+    """k_trace_persist_tlas (multi-BLAS scenes, BASELINE config 5's kernel) against the reference's own extend on the rays the reference's
+    own frame traced through two SBVH BLAS under a TLAS at bounces 0..6: t, primIdx, u, v, I, N bit for bit, and the reference's heat map
+    against the HIP `steps`.  The captured queues are tiled past 65,536 rays so that (with one workgroup per CU) the kernel's event loop
+    runs ("loop"; "loop-spill": LDS stack column capped at 6 entries, the rest in global memory); "flat" = its one-ray-per-lane branch
+    striding over the same queues."""
+    monkeypatch.setenv("RT355_TUNE", "64,20,6,8,1")
+    monkeypatch.setenv("RT355_TLAS_FLAT", "1,1" if mode == "flat" else "0,0")
+    monkeypatch.setenv("RT355_SPILL_CAP" if mode == "loop-spill" else "RT355_NO_SPILL", "6" if mode == "loop-spill" else "1")
+    s, view = scenes.two_blas_scene(alpha=0.0, n=24)
+    sa = s.arrays()
+    cam = scenes.camera_for(view, RW, RH)
+    ref = ref_gpu.RefGPU(sa, **DEFAULT)
+    cap = ref.frame_s0(cam, 364, 372)
+    d = Device(RW, RH, **DEFAULT)
+    d.upload(sa)
+    assert d.kernel_info()["persist"] == (3 if mode == "loop-spill" else 2)
+    d.enable_steps()
+    total = long_queues = 0
+    for b, ext in enumerate(cap["ext"]):
+        if len(ext) == 0:
+            continue
+        ext = np.tile(ext, -(-70000 // len(ext)) if b < 3 else 3)       # bounces 0-2 past the long-queue threshold, the rest short queues
+        long_queues += len(ext) > 65536
+        inp = ext.copy()
+        inp["t"], inp["primIdx"] = 1e30, -1                               # as initRay left them before the frame's own extend (ray.cl:4-19)
+        again, heat = ref.extend(inp, renderBVH=True)
+        assert_bits(again["t"], ext["t"], f"bounce {b}: the reference's extend, run again on the tiled queue")
+        d.set_rays(b, inp)
+        d.stage_extend(b)
+        got = d.get_rays(b)
+        hit = again["primIdx"] != -1
+        uv = hit & (sa.prims["objType"][np.where(hit, again["primIdx"], 0)] != 0)
+        for f in ("t", "primIdx", "I", "N"):
+            assert_bits(got[f], again[f], f"{mode}: bounce {b} extend {f}")
+        assert_bits(got["u"][uv], again["u"][uv], f"{mode}: bounce {b} extend u")
+        assert_bits(got["v"][uv], again["v"][uv], f"{mode}: bounce {b} extend v")
+        mine = d.get_steps()[:len(ext)]
+        assert np.array_equal(np.rint(heat[:, 0].astype(np.float64) * 255).astype(np.int32), mine), (mode, b)
+        d.enable_steps(False)                          # and the instantiation without the `steps` bookkeeping (the one a render runs)
+        d.set_rays(b, inp)
+        d.stage_extend(b)
+        lean = d.get_rays(b)
+        d.enable_steps(True)
+        for f in ("t", "primIdx", "u", "v", "I", "N"):
+            assert_bits(lean[f], got[f], f"{mode}: bounce {b} extend {f}: with and without steps")
+        total += len(ext)
+    assert long_queues >= 2 and total > 200000
+    c = d.counters()
+    assert c["extend_tlas_visits"] > 0 and c["extend_inst_visits"] > c["extend_rays"] // 2
     d.close()
     ref.close()
 
