@@ -653,7 +653,9 @@ static int configure_traversal(RtCtx* ctx)
     ctx->spillCap = backup ? kSpillCap - kBackupWords + 2 : kSpillCap;
     bool forceSpill = false;
     if (const char* t = getenv("RT355_SPILL_CAP")) { const int v = atoi(t); if (v >= 6 && v <= 64) { ctx->spillCap = v; forceSpill = true; } }
-    ctx->spillStack = ctx->persistTlas && (tlas_stack_entries(ctx) + (backup ? kBackupWords : 0) > kFitSeven || forceSpill) && tlas_stack_entries(ctx) > ctx->spillCap &&
+    // (columns of up to 22 entries stay whole in LDS, backup beside them: 5-6 workgroups per CU without the spill branches beat 7 with them,
+    // 1,923 against 1,849 and 1,327 against 1,310 M samples/s on two-BLAS scenes of 16 and 22 entries - tools/middepth_tlas.py)
+    ctx->spillStack = ctx->persistTlas && (tlas_stack_entries(ctx) > kFitSeven || forceSpill) && tlas_stack_entries(ctx) > ctx->spillCap &&
                       !(getenv("RT355_NO_SPILL") && atoi(getenv("RT355_NO_SPILL")));
     if (ctx->persistTlas && !ctx->spillStack && tlas_stack_entries(ctx) > RT_BVH4_STACK + 9) ctx->persistTlas = false;
     if (ctx->persist || ctx->persist4 || ctx->persistTlas) {

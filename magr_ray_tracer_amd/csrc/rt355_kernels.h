@@ -1093,7 +1093,14 @@ __global__ __launch_bounds__(kBlock, 7) void k_trace_persist_tlas(DevScene sc, D
         // loop's bookkeeping pays, but still want the seven workgroups per CU that the capped stack column allows.
         WorkCtr wc = { 0, 0, 0, 0 };
         uint32_t rays = 0;
-        for (int idx = waveId * 64 + lane; idx < n; idx += nWaves * 64) {
+        // primary rays: a wave takes an 8x8 pixel tile instead of 64 pixels of a scan line (see trace_short_queue) - any slot -> lane map
+        // is legal, every slot is traced on its own
+        const bool tiled = !OCC && b0 == 0 && n == q.nPix && ((q.width | (q.nPix / q.width)) & 7) == 0;
+        const int tilesX = q.width >> 3;
+        for (int item = waveId; item * 64 < n; item += nWaves) {
+            int idx = item * 64 + lane;
+            if (tiled) { const int ty = item / tilesX, tx = item - ty * tilesX; idx = ((ty << 3) + (lane >> 3)) * q.width + (tx << 3) + (lane & 7); }
+            if (idx >= n) continue;
             TRay r;
             float tmax;
             {
