@@ -845,11 +845,16 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
     if (ctx->persistTlas) {
         // bounce 0 with one workgroup per 256 rays: the kernel's short-queue branch = the nested one-ray-per-lane loops (coherent primary rays)
         const dim3 g = bounce > 0 || ctx->spillStack ? dim3(ctx->persistGrid) : grid_for(ctx->nPix);
+        // bounce 0 through the one-ray-per-lane branch: wave-uniform node records through the scalar cache (RT355_COHERENT=0: A/B runs)
+        static const bool cohOn = !(getenv("RT355_COHERENT") && atoi(getenv("RT355_COHERENT")) == 0);
+        const bool coh = cohOn && bounce == 0 && (ctx->tune.flat || !ctx->spillStack);
         if (ctx->spillStack) {
             if (wantSteps) LAUNCH(ctx, ST_EXTEND, (k_trace_persist_tlas<false, true, true>), g, tlas_stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+            else if (coh) LAUNCH(ctx, ST_EXTEND, (k_trace_persist_tlas<false, false, true, true>), g, tlas_stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
             else LAUNCH(ctx, ST_EXTEND, (k_trace_persist_tlas<false, false, true>), g, tlas_stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
         }
         else if (wantSteps) LAUNCH(ctx, ST_EXTEND, (k_trace_persist_tlas<false, true>), g, tlas_stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
+        else if (coh) LAUNCH(ctx, ST_EXTEND, (k_trace_persist_tlas<false, false, false, true>), g, tlas_stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
         else LAUNCH(ctx, ST_EXTEND, (k_trace_persist_tlas<false>), g, tlas_stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
     } else if (ctx->persist4)
         LAUNCH(ctx, ST_EXTEND, (k_trace_persist4<false>), bounce > 0 ? dim3(ctx->persistGrid) : grid_for(ctx->nPix), stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune4);

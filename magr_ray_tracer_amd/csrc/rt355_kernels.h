@@ -1072,7 +1072,10 @@ template <bool SPILL> RT_FORCEINLINE uint32_t stk_pop(const uint32_t* stk, const
     --sp;
     return (!SPILL || sp < q.stackCap) ? stk[sp * kBlock + threadIdx.x] : q.spill[(size_t)(sp - q.stackCap) * q.spillStride + gl];
 }
-template <bool OCC, bool STEPS = false, bool SPILL = false>
+// COH (extend of bounce 0 through the one-ray-per-lane branch): while every lane of the wave that is on an interior node is on the SAME
+// one - primary rays of an 8x8 pixel tile, the first levels of the TLAS and of each BLAS - its record comes once through the scalar cache
+// instead of 64 times through the vector memory pipeline (as in traverse_bvh2_packed_coherent; same arithmetic, order and counters).
+template <bool OCC, bool STEPS = false, bool SPILL = false, bool COH = false>
 __global__ __launch_bounds__(kBlock, 7) void k_trace_persist_tlas(DevScene sc, DevQueues q, int b0, int b1, int renderBVH, PersistTune tune)
 {
     const int kChunk = tune.chunk, kRefill = tune.refill, kInner = tune.inner, kLeafK = tune.leafK;
@@ -1148,10 +1151,10 @@ __global__ __launch_bounds__(kBlock, 7) void k_trace_persist_tlas(DevScene sc, D
                 } else {
                     const bool isT = (cur & kTagTlas) != 0u;
                     if (isT) wc.tlas++; else wc.node++;
-                    const float4* p = (isT ? sc.tlasPairsP : sc.pairs) + (size_t)(cur & kIdMask) * 4;
-                    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                    uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
                     if (OCC) {
+                        const float4* p = (isT ? sc.tlasPairsP : sc.pairs) + (size_t)(cur & kIdMask) * 4;
+                        const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                        const uint32_t e1 = __float_as_uint(q3.x), e2 = __float_as_uint(q3.y);
                         float n1, x1, n2, x2;
                         const bool h1 = slab_both(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f), n1, x1);
                         const bool h2 = slab_both(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f), n2, x2);
@@ -1159,8 +1162,22 @@ __global__ __launch_bounds__(kBlock, 7) void k_trace_persist_tlas(DevScene sc, D
                         else if (h1 || h2) cur = h1 ? e1 : e2;
                         else needPop = true;
                     } else {
-                        float d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
-                        float d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
+                        float d1, d2;
+                        uint32_t e1, e2;
+                        const uint32_t ucur = COH ? __builtin_amdgcn_readfirstlane(cur) : 0u;
+                        if (COH && __ballot(cur != ucur) == 0ull) {   // (the slab tests are written out here too: they read the record from scalar registers)
+                            const ConstF4 cp = (ConstF4)(uintptr_t)((ucur & kTagTlas) != 0u ? sc.tlasPairsP : sc.pairs) + (size_t)(ucur & kIdMask) * 4;
+                            const fvec4 a = cp[0], b = cp[1], c = cp[2], d = cp[3];
+                            d1 = slab(r, mk4(a.x, a.y, a.z, 0.0f), mk4(a.w, b.x, b.y, 0.0f));
+                            d2 = slab(r, mk4(b.z, b.w, c.x, 0.0f), mk4(c.y, c.z, c.w, 0.0f));
+                            e1 = __float_as_uint(d.x); e2 = __float_as_uint(d.y);
+                        } else {
+                            const float4* p = (isT ? sc.tlasPairsP : sc.pairs) + (size_t)(cur & kIdMask) * 4;
+                            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                            d1 = slab(r, mk4(q0.x, q0.y, q0.z, 0.0f), mk4(q0.w, q1.x, q1.y, 0.0f));
+                            d2 = slab(r, mk4(q1.z, q1.w, q2.x, 0.0f), mk4(q2.y, q2.z, q2.w, 0.0f));
+                            e1 = __float_as_uint(q3.x); e2 = __float_as_uint(q3.y);
+                        }
                         if (d1 > d2) { float d = d1; d1 = d2; d2 = d; uint32_t e = e1; e1 = e2; e2 = e; }
                         if (d1 >= tLight) needPop = true;
                         else {
