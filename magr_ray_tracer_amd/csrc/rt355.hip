@@ -685,6 +685,7 @@ static int configure_traversal(RtCtx* ctx)
             if (k >= 4 && a > 0 && b > 0 && b <= 64 && c > 0 && l > 0 && l <= 64) ctx->tune = ctx->tuneConnect = ctx->tune4 = PersistTune{ a, b, c, l, 0, 0 };
             if (k == 5 && d > 0) ctx->persistGrid = ctx->persistGridConnect = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount);
         }
+        if (const char* t = getenv("RT355_CONNECT_BLOCKS")) { const int d = atoi(t); if (d > 0) ctx->persistGridConnect = std::min(ctx->gridMax, std::min(d, std::max(1, perCU)) * prop.multiProcessorCount); }   // (lab)
         if (const char* t = getenv("RT355_FIXED_CHUNKS")) { int a = 0, b = 0; if (sscanf(t, "%d,%d", &a, &b) == 2) { ctx->tune.fixedChunks = ctx->tune4.fixedChunks = a; ctx->tuneConnect.fixedChunks = b; } }   // extend, connect (tuning aid)
         if (const char* t = getenv("RT355_TUNE_CONNECT")) { // same fields, connect launches only
             int a = 0, b = 0, c = 0, l = 0;
@@ -846,8 +847,8 @@ extern "C" int rt_stage_extend(RtCtx* ctx, int32_t bounce, int32_t renderBVH)
         // bounce 0 with one workgroup per 256 rays: the kernel's short-queue branch = the nested one-ray-per-lane loops (coherent primary rays)
         const dim3 g = bounce > 0 || ctx->spillStack ? dim3(ctx->persistGrid) : grid_for(ctx->nPix);
         // bounce 0 through the one-ray-per-lane branch: wave-uniform node records through the scalar cache (RT355_COHERENT=0: A/B runs)
-        static const bool cohOn = !(getenv("RT355_COHERENT") && atoi(getenv("RT355_COHERENT")) == 0);
-        const bool coh = cohOn && bounce == 0 && (ctx->tune.flat || !ctx->spillStack);
+        static const int cohOn = getenv("RT355_COHERENT") ? atoi(getenv("RT355_COHERENT")) : 1;   // (2: every bounce - lab)
+        const bool coh = cohOn && (bounce == 0 || cohOn == 2) && (ctx->tune.flat || !ctx->spillStack);
         if (ctx->spillStack) {
             if (wantSteps) LAUNCH(ctx, ST_EXTEND, (k_trace_persist_tlas<false, true, true>), g, tlas_stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
             else if (coh) LAUNCH(ctx, ST_EXTEND, (k_trace_persist_tlas<false, false, true, true>), g, tlas_stack_bytes(ctx), ctx->sc, ctx->q, bounce, bounce, renderBVH, ctx->tune);
