@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "../../include/rt355.h"
@@ -65,6 +66,7 @@ struct RtCtx {
     bool persistTlas = false;   // ... through a multi-BLAS TLAS (BVH2, layout 1): k_trace_persist_tlas
     bool spillStack = false;    // ... with the deep end of the traversal stacks in global memory (trees deeper than the LDS share of 7 workgroups per CU)
     uint32_t* dSpill = nullptr; size_t spillWords = 0;
+    int xcdFirst = -1;      // the XCD this context's sparse queues start on (PersistTune.xcdFirst)
     int spillCap = kSpillCap;   // LDS entries per lane of a spilling kernel (RT355_SPILL_CAP: tests force the spill path with a tiny cap, >= 6)
     int nInterior = 0;          // records of the dense pair table (their ids must fit the 29-bit field of the tagged stack entries)
     bool cursorUsed[2 * (RT_MAX_BOUNCES + 2)] = {};   // work-queue heads consumed since the last k_begin_frame
@@ -702,6 +704,17 @@ static int configure_traversal(RtCtx* ctx)
         ctx->tune.flat = 1; ctx->tuneConnect.flat = 0;
         ctx->tune.backup = ctx->tuneConnect.backup = backup ? 1 : 0;   // (set here, after RT355_TUNE has been parsed: that assignment resets the struct)
         if (const char* t = getenv("RT355_TLAS_FLAT")) { int a = 0, b = 0; if (sscanf(t, "%d,%d", &a, &b) == 2) { ctx->tune.flat = a; ctx->tuneConnect.flat = b; } }
+    }
+    // sparse queues (the one-ray-per-lane branches) stay on as few XCDs as hold them at 16,384 rays each, so that their rays share an L2:
+    // config 2's late launches 99 / 82 / 70 / 53 -> 90 / 73 / 66 / 47 us (EXPERIMENTS.md (54)); contexts start on different XCDs.
+    // (set here, after RT355_TUNE has been parsed: that assignment resets the struct)
+    {
+        static std::atomic<int> serial{ 0 };
+        if (ctx->xcdFirst < 0) ctx->xcdFirst = serial.fetch_add(1) & 7;
+        int rays = 16384;
+        if (const char* t = getenv("RT355_XCD_RAYS")) rays = std::max(0, atoi(t));
+        ctx->tune.xcdRays = ctx->tuneConnect.xcdRays = ctx->tune4.xcdRays = rays;
+        ctx->tune.xcdFirst = ctx->tuneConnect.xcdFirst = ctx->tune4.xcdFirst = ctx->xcdFirst;
     }
     ctx->q.spill = nullptr; ctx->q.spillStride = 0; ctx->q.stackCap = 0;
     ctx->q.tlasLdsEntries = ctx->persistTlas ? (uint32_t)tlas_lds_entries(ctx) : 0u;

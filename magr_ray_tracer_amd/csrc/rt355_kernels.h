@@ -833,18 +833,38 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int
 static constexpr int kTpWaves = 8192;
 __device__ unsigned long long g_tp[9][kTpWaves][4];
 #endif
-struct PersistTune { int chunk, refill, inner, leafK, fixedChunks, flat = 0, backup = 0; };   // backup: k_trace_persist_tlas keeps the world ray in LDS across an instance visit (10 words per lane behind the stack column) instead of fetching it back from the queue   // flat: k_trace_persist_tlas runs every queue through its one-ray-per-lane branch, 64 rays per wave and round (short traversals: config 5's open scene)   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path, chunks dealt round-robin instead of dequeued
+struct PersistTune { int chunk, refill, inner, leafK, fixedChunks, flat = 0, backup = 0, xcdRays = 0, xcdFirst = 0; };   // xcdRays: a sparse queue's rays are kept on as few XCDs as hold them at this many rays each (one-ray-per-lane branches; 0 = spread over all eight)   // backup: k_trace_persist_tlas keeps the world ray in LDS across an instance visit (10 words per lane behind the stack column) instead of fetching it back from the queue   // flat: k_trace_persist_tlas runs every queue through its one-ray-per-lane branch, 64 rays per wave and round (short traversals: config 5's open scene)   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path, chunks dealt round-robin instead of dequeued
+
+// A sparse queue on few XCDs: workgroup ids go to the eight XCDs round-robin and every XCD has its own L2, so the few thousand rays of a late
+// bounce spread over all of them fetch every node record from the Infinity Cache once PER XCD.  With `xcdRays` > 0 only the workgroups of
+// the first nx XCDs take rays (nx = as many as hold the queue at xcdRays rays each), in the order of their rank among those: returns the
+// wave's rank and sets `waves` to the number of participating waves, or -1 for a wave that sits this launch out.
+RT_FORCEINLINE int xcd_pack(int n, int xcdRays, int xcdFirst, int& waves)
+{
+    const int wpb = kBlock / 64, wave = threadIdx.x >> 6;
+    waves = gridDim.x * wpb;
+    if (xcdRays <= 0 || (gridDim.x & 7u) != 0u) return blockIdx.x * wpb + wave;
+    const int perXcd = (int)(gridDim.x >> 3) * kBlock;
+    int nx = min(8, max(1, (n + xcdRays - 1) / xcdRays));
+    while (nx < 8 && (long long)nx * perXcd < (long long)n) nx++;
+    if (nx == 8) return blockIdx.x * wpb + wave;
+    const int xcd = (int)(blockIdx.x + 8u - (uint32_t)xcdFirst) & 7;   // contexts that share the GPU start on different XCDs
+    waves = (int)(gridDim.x >> 3) * nx * wpb;
+    if (xcd >= nx) return -1;
+    return ((int)(blockIdx.x >> 3) * nx + xcd) * wpb + wave;
+}
 
 // Short queue (late bounces, and bounce 0 when it is launched with one workgroup per 256 rays): every wave gets at most one 64-ray chunk
 // and nothing is left to refill from, so run the plain one-ray-per-lane loop, which has less per-step overhead than the refill machine.
 template <bool OCC, bool COH>
 RT_FORCEINLINE void trace_short_queue(const DevScene& sc, const DevQueues& q, int b0, int qFirst, int n, int renderBVH, const float* T,
-                                      uint32_t rootEntry, uint32_t* stk, int waveId, int lane)
+                                      uint32_t rootEntry, uint32_t* stk, int waveId, int lane, int xcdRays = 0, int xcdFirst = 0)
 {
     WorkCtr wc = { 0, 0, 0, 0 };
     uint32_t rays = 0;
     TRay r; r.t = 0; r.prim = -1; r.u = r.v = 0; r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.rx = r.ry = r.rz = 0;
     int idx = waveId * 64 + lane;
+    if (xcdRays > 0 && !(b0 == 0 && n == q.nPix)) { int waves; const int w = xcd_pack(n, xcdRays, xcdFirst, waves); idx = w < 0 ? n : w * 64 + lane; }
     if (!OCC && b0 == 0 && ((q.width | (q.nPix / q.width)) & 7) == 0 && n == q.nPix && (long long)gridDim.x * kBlock >= (long long)q.nPix) {
         // primary rays: a wave takes an 8x8 pixel tile instead of a 64x1 strip (the queue of bounce 0 is the pixel grid - only when it IS
         // the whole grid and the launch has a wave for every tile; an injected shorter queue or a smaller grid keeps the strip mapping)
@@ -907,7 +927,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
 #define TAIL_PROBE_EXIT() if (lane == 0 && waveId < kTpWaves) { unsigned long long* w = g_tp[OCC ? 8 : b0][waveId]; w[0] = tp0; w[1] = tpDry; w[2] = wall_clock64(); w[3] = rays; }
 #endif
     if (n <= nWaves * 64) {
-        trace_short_queue<OCC, COH>(sc, q, b0, qFirst, n, renderBVH, T, rootEntry, stk, waveId, lane);
+        trace_short_queue<OCC, COH>(sc, q, b0, qFirst, n, renderBVH, T, rootEntry, stk, waveId, lane, tune.xcdRays, tune.xcdFirst);
 #ifdef RT355_TAIL_PROBE
         TAIL_PROBE_EXIT()
 #endif
@@ -1100,7 +1120,9 @@ __global__ __launch_bounds__(kBlock, 7) void k_trace_persist_tlas(DevScene sc, D
         // is legal, every slot is traced on its own
         const bool tiled = !OCC && b0 == 0 && n == q.nPix && ((q.width | (q.nPix / q.width)) & 7) == 0;
         const int tilesX = q.width >> 3;
-        for (int item = waveId; item * 64 < n; item += nWaves) {
+        int packWaves = nWaves;
+        const int packId = tune.xcdRays > 0 && !tiled ? xcd_pack(n, tune.xcdRays, tune.xcdFirst, packWaves) : waveId;   // a sparse queue on few XCDs
+        for (int item = packId < 0 ? n : packId; item * 64 < n; item += packWaves) {
             int idx = item * 64 + lane;
             if (tiled) { const int ty = item / tilesX, tx = item - ty * tilesX; idx = ((ty << 3) + (lane >> 3)) * q.width + (tx << 3) + (lane & 7); }
             if (idx >= n) continue;
