@@ -3,6 +3,8 @@
 //   calib_gather  dependent random 64-byte record fetches, 4 x global_load_dwordx4 per lane and record (the traversal's node event),
 //                 from a table that fits the L2s (4 MB) / the Infinity Cache only (64 MB): lanes x steps x 64 B known exactly
 //   calib_store   a coalesced streaming store, 16 B per lane
+//   calib_reread  <0> and <1>: the same 2 MB table read by every workgroup in two back-to-back launches - do the L2s keep it?  (no: both
+//                 miss 2 MB / 128 B x 8 XCDs times)
 //   calib_valu    nothing but vector arithmetic: 4 independent chains of v_fma_f32 per lane, 8 waves per SIMD; the number of wave-level
 //                 vector instructions is known exactly (waves x iterations x 64 + a few) -> the unit of SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU /
 //                 SQ_WAVE_CYCLES (quad-cycles?) and the issue peak of the chip (one wave64 instruction per SIMD every 4 clocks)
@@ -72,6 +74,17 @@ __global__ __launch_bounds__(256) void calib_valu_mix(float* out, int iters, flo
     out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3;
 }
 
+// Does an XCD's L2 keep a read-only table from one launch to the next?  Two launches of the same read (different names), every workgroup
+// reads the whole 2 MB table: TCC_MISS of the second against the first.
+template <int TAG>
+__global__ __launch_bounds__(256) void calib_reread(const float4* __restrict__ tab, int n4, float* out)
+{
+    float acc = 0;
+    for (int rep = 0; rep < 2; rep++)
+        for (int i = threadIdx.x; i < n4; i += 256) { const float4 v = tab[i]; acc += v.x + v.w; }
+    if (acc == 12345.678f) out[blockIdx.x] = acc;
+}
+
 int main()
 {
     const size_t streamBytes = (size_t)1 << 30;          // 1 GiB
@@ -102,6 +115,12 @@ int main()
         }
         CHK(hipDeviceSynchronize());
     }
+    CHK(hipMemset(buf, 0, 2 << 20));
+    CHK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(calib_reread<0>, dim3(256), dim3(256), 0, 0, buf, (2 << 20) / 16, out);
+    hipLaunchKernelGGL(calib_reread<1>, dim3(256), dim3(256), 0, 0, buf, (2 << 20) / 16, out);
+    CHK(hipDeviceSynchronize());
+    printf("calib_reread<0>, <1>: 256 workgroups each read a 2 MB table twice; <1> is launched right after <0> on the same stream\n");
     const int valuIters = 4096, valuBlocks = 256 * 8;
     for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(calib_valu, dim3(valuBlocks), dim3(256), 0, 0, out, valuIters, 0.999f, 0.001f);
     for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(calib_valu_mix, dim3(valuBlocks), dim3(256), 0, 0, out, valuIters, 0.999f, 0.001f);
