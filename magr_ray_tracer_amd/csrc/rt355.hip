@@ -705,16 +705,20 @@ static int configure_traversal(RtCtx* ctx)
         ctx->tune.backup = ctx->tuneConnect.backup = backup ? 1 : 0;   // (set here, after RT355_TUNE has been parsed: that assignment resets the struct)
         if (const char* t = getenv("RT355_TLAS_FLAT")) { int a = 0, b = 0; if (sscanf(t, "%d,%d", &a, &b) == 2) { ctx->tune.flat = a; ctx->tuneConnect.flat = b; } }
     }
-    // sparse queues (the one-ray-per-lane branches) stay on as few XCDs as hold them at 16,384 rays each, so that their rays share an L2:
-    // config 2's late launches 99 / 82 / 70 / 53 -> 90 / 73 / 66 / 47 us (EXPERIMENTS.md (54)); contexts start on different XCDs.
+    // sparse queues (the one-ray-per-lane branches) stay on as few XCDs as hold them at 1,024 rays each, so that their rays share an L2
+    // (EXPERIMENTS.md (54): 16,384 before the thinning below made spreading the better default); contexts start on different XCDs.
     // (set here, after RT355_TUNE has been parsed: that assignment resets the struct)
     {
         static std::atomic<int> serial{ 0 };
         if (ctx->xcdFirst < 0) ctx->xcdFirst = serial.fetch_add(1) & 7;
-        int rays = 16384;
+        int rays = 1024;
         if (const char* t = getenv("RT355_XCD_RAYS")) rays = std::max(0, atoi(t));
         ctx->tune.xcdRays = ctx->tuneConnect.xcdRays = ctx->tune4.xcdRays = rays;
         ctx->tune.xcdFirst = ctx->tuneConnect.xcdFirst = ctx->tune4.xcdFirst = ctx->xcdFirst;
+        // ... and on few lanes of every participating wave when they hold at most 16 rays per wave (sparse_slot; RT355_THIN=0: off)
+        int thin = 16;
+        if (const char* t = getenv("RT355_THIN")) thin = std::min(64, std::max(0, atoi(t)));
+        ctx->tune.thin = ctx->tuneConnect.thin = ctx->tune4.thin = thin;
     }
     ctx->q.spill = nullptr; ctx->q.spillStride = 0; ctx->q.stackCap = 0;
     ctx->q.tlasLdsEntries = ctx->persistTlas ? (uint32_t)tlas_lds_entries(ctx) : 0u;

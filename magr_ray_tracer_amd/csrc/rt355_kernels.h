@@ -833,7 +833,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DevScene sc, DevQueues q, int
 static constexpr int kTpWaves = 8192;
 __device__ unsigned long long g_tp[9][kTpWaves][4];
 #endif
-struct PersistTune { int chunk, refill, inner, leafK, fixedChunks, flat = 0, backup = 0, xcdRays = 0, xcdFirst = 0; };   // xcdRays: a sparse queue's rays are kept on as few XCDs as hold them at this many rays each (one-ray-per-lane branches; 0 = spread over all eight)   // backup: k_trace_persist_tlas keeps the world ray in LDS across an instance visit (10 words per lane behind the stack column) instead of fetching it back from the queue   // flat: k_trace_persist_tlas runs every queue through its one-ray-per-lane branch, 64 rays per wave and round (short traversals: config 5's open scene)   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path, chunks dealt round-robin instead of dequeued
+struct PersistTune { int chunk, refill, inner, leafK, fixedChunks, flat = 0, backup = 0, xcdRays = 0, xcdFirst = 0, thin = 0; };   // thin: a queue of at most `thin` rays per participating wave is spread evenly over the waves (few lanes of each) instead of filling the first waves   // xcdRays: a sparse queue's rays are kept on as few XCDs as hold them at this many rays each (one-ray-per-lane branches; 0 = spread over all eight)   // backup: k_trace_persist_tlas keeps the world ray in LDS across an instance visit (10 words per lane behind the stack column) instead of fetching it back from the queue   // flat: k_trace_persist_tlas runs every queue through its one-ray-per-lane branch, 64 rays per wave and round (short traversals: config 5's open scene)   // rays per dequeue, idle lanes that trigger a top-up, events between checks, lanes on a leaf that trigger the triangle path, chunks dealt round-robin instead of dequeued
 
 // A sparse queue on few XCDs: workgroup ids go to the eight XCDs round-robin and every XCD has its own L2, so the few thousand rays of a late
 // bounce spread over all of them fetch every node record from the Infinity Cache once PER XCD.  With `xcdRays` > 0 only the workgroups of
@@ -854,17 +854,33 @@ RT_FORCEINLINE int xcd_pack(int n, int xcdRays, int xcdFirst, int& waves)
     return ((int)(blockIdx.x >> 3) * nx + xcd) * wpb + wave;
 }
 
+// The queue slot of this lane in a launch that is not shorter than its queue (the one-ray-per-lane loops), or n for a lane without one.
+// Sparse queues are (1) kept on few XCDs (xcd_pack) and (2) THINNED: in the one-ray-per-lane loop a wave pays for the union of its lanes'
+// states every iteration - a node fetch AND a leaf's triangle fetches, one after the other - so a ray advances at the pace of its 63
+// wave-mates; a queue of at most `thin` rays per participating wave therefore takes a few lanes of EVERY wave instead of all lanes of the
+// first ones (config 2's late launches 93 / 88 / 72 / 65 / 48 -> 83 / 60 / 38 / 33 / 29 us, EXPERIMENTS.md (55)).
+RT_FORCEINLINE int sparse_slot(int n, const PersistTune& t, int waveId, int lane)
+{
+    if (t.xcdRays <= 0 && t.thin <= 0) return waveId * 64 + lane;
+    int waves;
+    const int w = xcd_pack(n, t.xcdRays, t.xcdFirst, waves);
+    if (w < 0) return n;
+    const int per = (n + waves - 1) / waves;      // (<= 64: the queue is not longer than the launch)
+    if (t.thin > 0 && per <= t.thin) return lane < per ? w * per + lane : n;
+    return w * 64 + lane;
+}
+
 // Short queue (late bounces, and bounce 0 when it is launched with one workgroup per 256 rays): every wave gets at most one 64-ray chunk
 // and nothing is left to refill from, so run the plain one-ray-per-lane loop, which has less per-step overhead than the refill machine.
 template <bool OCC, bool COH>
 RT_FORCEINLINE void trace_short_queue(const DevScene& sc, const DevQueues& q, int b0, int qFirst, int n, int renderBVH, const float* T,
-                                      uint32_t rootEntry, uint32_t* stk, int waveId, int lane, int xcdRays = 0, int xcdFirst = 0)
+                                      uint32_t rootEntry, uint32_t* stk, int waveId, int lane, const PersistTune& tune)
 {
     WorkCtr wc = { 0, 0, 0, 0 };
     uint32_t rays = 0;
     TRay r; r.t = 0; r.prim = -1; r.u = r.v = 0; r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.rx = r.ry = r.rz = 0;
     int idx = waveId * 64 + lane;
-    if (xcdRays > 0 && !(b0 == 0 && n == q.nPix)) { int waves; const int w = xcd_pack(n, xcdRays, xcdFirst, waves); idx = w < 0 ? n : w * 64 + lane; }
+    if (!(b0 == 0 && n == q.nPix)) idx = sparse_slot(n, tune, waveId, lane);
     if (!OCC && b0 == 0 && ((q.width | (q.nPix / q.width)) & 7) == 0 && n == q.nPix && (long long)gridDim.x * kBlock >= (long long)q.nPix) {
         // primary rays: a wave takes an 8x8 pixel tile instead of a 64x1 strip (the queue of bounce 0 is the pixel grid - only when it IS
         // the whole grid and the launch has a wave for every tile; an injected shorter queue or a smaller grid keeps the strip mapping)
@@ -927,7 +943,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist(DevScene sc, DevQueues
 #define TAIL_PROBE_EXIT() if (lane == 0 && waveId < kTpWaves) { unsigned long long* w = g_tp[OCC ? 8 : b0][waveId]; w[0] = tp0; w[1] = tpDry; w[2] = wall_clock64(); w[3] = rays; }
 #endif
     if (n <= nWaves * 64) {
-        trace_short_queue<OCC, COH>(sc, q, b0, qFirst, n, renderBVH, T, rootEntry, stk, waveId, lane, tune.xcdRays, tune.xcdFirst);
+        trace_short_queue<OCC, COH>(sc, q, b0, qFirst, n, renderBVH, T, rootEntry, stk, waveId, lane, tune);
 #ifdef RT355_TAIL_PROBE
         TAIL_PROBE_EXIT()
 #endif
@@ -1121,11 +1137,14 @@ __global__ __launch_bounds__(kBlock, 7) void k_trace_persist_tlas(DevScene sc, D
         const bool tiled = !OCC && b0 == 0 && n == q.nPix && ((q.width | (q.nPix / q.width)) & 7) == 0;
         const int tilesX = q.width >> 3;
         int packWaves = nWaves;
-        const int packId = tune.xcdRays > 0 && !tiled ? xcd_pack(n, tune.xcdRays, tune.xcdFirst, packWaves) : waveId;   // a sparse queue on few XCDs
-        for (int item = packId < 0 ? n : packId; item * 64 < n; item += packWaves) {
-            int idx = item * 64 + lane;
+        const int packId = (tune.xcdRays > 0 || tune.thin) && !tiled ? xcd_pack(n, tune.xcdRays, tune.xcdFirst, packWaves) : waveId;   // a sparse queue on few XCDs
+        // ... and on few lanes of every participating wave (see trace_short_queue)
+        int per = 64;
+        if (tune.thin > 0 && !tiled && (long long)packWaves * tune.thin >= (long long)n) per = max(1, (n + packWaves - 1) / packWaves);
+        for (int item = packId < 0 ? n : packId; (long long)item * per < (long long)n; item += packWaves) {
+            int idx = item * per + lane;
             if (tiled) { const int ty = item / tilesX, tx = item - ty * tilesX; idx = ((ty << 3) + (lane >> 3)) * q.width + (tx << 3) + (lane & 7); }
-            if (idx >= n) continue;
+            if (lane >= per || idx >= n) continue;
             TRay r;
             float tmax;
             {
@@ -1449,7 +1468,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_persist4(DevScene sc, DevQueue
     };
 
     if (n <= nWaves * 64) {   // short queue: plain one-ray-per-lane loop
-        int idx = waveId * 64 + lane;
+        int idx = b0 == 0 && n == q.nPix ? waveId * 64 + lane : sparse_slot(n, tune, waveId, lane);
         if (!OCC && b0 == 0 && ((q.width | (q.nPix / q.width)) & 7) == 0 && n == q.nPix && (long long)gridDim.x * kBlock >= (long long)q.nPix) {   // primary rays: 8x8 pixel tile per wave (see trace_short_queue)
             const int tilesX = q.width >> 3, ty = waveId / tilesX, tx = waveId - ty * tilesX;
             idx = ((ty << 3) + (lane >> 3)) * q.width + (tx << 3) + (lane & 7);
