@@ -47,13 +47,13 @@ MIN_TIMED_S = 0.25      # repeat the K-step region until this much has been time
 # metric is quoted on; the others are parity-test cases that can be timed / profiled with --config (tools/r3_pmc.sh).
 CONFIGS = {
     2: dict(label="bunny-class closed mesh, Kajiya (SHADING_SIMPLE)", scene=lambda a: __import__("magr_ray_tracer_amd.scenes", fromlist=["x"]).bunny_class(187),
-            W=1280, H=720, spp=64, accel="bvh2", shading=0, lanes=6),
+            W=1280, H=720, spp=64, accel="bvh2", shading=0, lanes=8),
     3: dict(label="sponza-class procedural atrium", scene=lambda a: __import__("magr_ray_tracer_amd.scenes", fromlist=["x"]).sponza_class(a.detail),
             W=1920, H=1080, spp=256, accel="bvh2", shading=1),
     4: dict(label="sponza-class procedural atrium through the QBVH", scene=lambda a: __import__("magr_ray_tracer_amd.scenes", fromlist=["x"]).sponza_class(a.detail),
             W=1920, H=1080, spp=1024, accel="bvh4", shading=1),
     5: dict(label="robo-orb + terrarium_bot, two BLAS under a TLAS, SBVH alpha 0", scene=lambda a: __import__("magr_ray_tracer_amd.scenes", fromlist=["x"]).config5_scene(0.0),
-            W=3840, H=2160, spp=4096, accel="bvh2", shading=1, lanes=6),
+            W=3840, H=2160, spp=4096, accel="bvh2", shading=1, lanes=8),
 }
 
 
@@ -80,7 +80,7 @@ def parse_args():
     ap.add_argument("--shard", choices=["samples", "bands", "ibands"], default="samples")
     ap.add_argument("--band-rows", type=int, default=0, help="ibands: rows per band (0 = a quarter of a rank's contiguous share)")
     ap.add_argument("--persist-blocks", type=int, default=0, help="workgroups per CU of the persistent traversal grids of lanes that share the GPU (0 = the library's choice, 2)")
-    ap.add_argument("--lanes", type=int, default=0, help="sample streams per GPU (and per row band) whose frames overlap; 0 = 4 (configs 2 and 5, whose late launches are nearly empty: 6; ibands: 1), 1 = the reference's single in-order queue")
+    ap.add_argument("--lanes", type=int, default=0, help="sample streams per GPU (and per row band) whose frames overlap; 0 = 4 (configs 2 and 5, whose late launches are nearly empty: 8; ibands: 1), 1 = the reference's single in-order queue")
     ap.add_argument("--extend-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket stage launches with HIP events")

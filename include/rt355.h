@@ -140,7 +140,7 @@ int rt_share_scene(RtCtx* ctx, RtCtx* from);
  * sample stream firstStream + m (seeds = that slice of the reference's host xorshift32 stream, renderer.cpp:195-196); the group's
  * accumulator is the sum of the lanes' accumulators in lane order and, after k frames in all, holds k samples per pixel - prep()
  * divides by k exactly as with one stream (postproc.cl:71).  A group of ONE lane is the reference's single Renderer bit for bit.
- * HIP runs kernels of streams that share a hardware queue one after the other: the library asks for GPU_MAX_HW_QUEUES=8 when it is
+ * HIP runs kernels of streams that share a hardware queue one after the other: the library asks for GPU_MAX_HW_QUEUES=16 when it is
  * loaded (effective if HIP has not been initialised yet), rt_group_create measures how many of the group's streams really run side
  * by side (rt_group_concurrency) and writes one line to stderr when that is fewer than `lanes`. */
 typedef struct RtGroup RtGroup;

@@ -1216,9 +1216,9 @@ extern "C" int rt_postproc(RtCtx* ctx, int32_t frames, float vignette, float gam
 // lane order.  (Reference: one Renderer, one in-order queue, renderer.cpp:26-94; the group is what stands behind Renderer::Tick here.)
 //
 // HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, the null stream included) and runs kernels of streams
-// that share one after the other.  The library asks for 8 when it is loaded (before HIP initialises, unless the application already
-// did), and rt_group_create MEASURES how many of its streams really run side by side, so a caller is told instead of silently serialised.
-__attribute__((constructor)) static void rt355_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// that share one after the other.  The library asks for 16 when it is loaded (before HIP initialises, unless the application already
+// did; eight lanes + the process's own streams + RCCL's need more than 8: with 8 queues eight lanes run four at a time), and rt_group_create MEASURES how many of its streams really run side by side, so a caller is told instead of silently serialised.
+__attribute__((constructor)) static void rt355_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 __global__ void k_spin(long long ticks, int* sink)
 {

@@ -43,7 +43,9 @@ RUNS = {
     "config4_lanes4": ("--config 4", dict(config=4, accel="bvh4", detail=1.0, width=1920, height=1080, model=False, lanes=4)),
     "config5_lanes1": ("--config 5 --lanes 1", dict(config=5, accel="bvh2", detail=1.0, width=3840, height=2160, model=False, lanes=1)),
     "config5_lanes4": ("--config 5 --lanes 4", dict(config=5, accel="bvh2", detail=1.0, width=3840, height=2160, model=False, lanes=4)),
-    "config5_lanes6": ("--config 5", dict(config=5, accel="bvh2", detail=1.0, width=3840, height=2160, model=False, lanes=6)),
+    "config5_lanes6": ("--config 5 --lanes 6", dict(config=5, accel="bvh2", detail=1.0, width=3840, height=2160, model=False, lanes=6)),
+    "config5_lanes8": ("--config 5", dict(config=5, accel="bvh2", detail=1.0, width=3840, height=2160, model=False, lanes=8)),
+    "config2_lanes8": ("--config 2", dict(config=2, accel="bvh2", detail=1.0, width=1280, height=720, model=False, lanes=8)),
     "config2_lanes1": ("--config 2 --lanes 1", dict(config=2, accel="bvh2", detail=1.0, width=1280, height=720, model=False, lanes=1)),
 }
 EXTEND = ("k_trace_persist<false", "k_trace_persist4<false", "k_trace_persist_tlas<false", "k_extend<")
