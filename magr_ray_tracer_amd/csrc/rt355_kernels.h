@@ -479,12 +479,14 @@ RT_FORCEINLINE int traverse_bvh2_packed(const DevScene& sc, TRay& r, uint32_t ro
     const float tLight = r.t;
     for (;;) {
         if (cur & kLeafBit) {
+            // ONE triangle of the leaf per iteration (the rest of the leaf stays in `cur`): a wave of this loop runs the leaf body whenever
+            // any of its lanes is on a leaf, and with the whole leaf in that body every such iteration cost the lanes on a box pair two or
+            // three dependent triangle fetches (config 3's late bounces 195 / 147 / 127 -> 184 / 138 / 116 us, EXPERIMENTS.md (57))
             const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
-            for (uint32_t i = 0; i < count; i++) {
-                wc.prim++;
-                test_tri_packed(sc, first + i, r);
-                if (OCC && r.t < tLight) return -1;
-            }
+            wc.prim++;
+            test_tri_packed(sc, first, r);
+            if (OCC && r.t < tLight) return -1;
+            if (count > 1) { cur = kLeafBit | ((count - 1) << 24) | (first + 1); continue; }
             if (sp == 0) break;
             cur = STK(--sp);
             continue;
@@ -531,7 +533,8 @@ RT_FORCEINLINE int traverse_bvh2_packed_coherent(const DevScene& sc, TRay& r, ui
     for (;;) {
         if (cur & kLeafBit) {
             const uint32_t first = cur & 0x00ffffffu, count = (cur >> 24) & 0x7fu;
-            for (uint32_t i = 0; i < count; i++) { wc.prim++; test_tri_packed(sc, first + i, r); }
+            wc.prim++; test_tri_packed(sc, first, r);        // one triangle per iteration, as in traverse_bvh2_packed
+            if (count > 1) { cur = kLeafBit | ((count - 1) << 24) | (first + 1); continue; }
             if (sp == 0) break;
             cur = STK(--sp);
             continue;
