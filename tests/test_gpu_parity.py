@@ -555,6 +555,37 @@ def test_instance_transform_non_identity_bit_exact():
         d.close()
 
 
+_SPARSE_CACHE = {}
+
+
+@pytest.mark.parametrize("scene", ["one_blas", "one_blas_bvh4", "two_blas"])
+@pytest.mark.parametrize("thin,xcd", [("0", "0"), ("16", "1024"), ("64", "0"), ("4", "64"), ("1", "16384")])
+def test_sparse_queues_any_slot_to_lane_map_is_the_same_frame(scene, thin, xcd, monkeypatch):
+    """Where a queue slot is traced is free (every slot is traced on its own): the one-ray-per-lane branches keep sparse queues on few XCDs
+    (RT355_XCD_RAYS) and on few lanes of every wave (RT355_THIN).  A small frame whose late bounces hold from tens of thousands of rays
+    down to a handful, with the two switched off, at their defaults and at extreme values: accumulator, RNG states, work counters and
+    the per-pixel `steps` of the last extend must equal the oracle's every time."""
+    monkeypatch.setenv("RT355_THIN", thin)
+    monkeypatch.setenv("RT355_XCD_RAYS", xcd)
+    Wd, Hd = 480, 270
+    v = dict(DEFAULT, accel=1 if scene == "one_blas_bvh4" else 0)
+    if scene not in _SPARSE_CACHE:
+        s, view = scenes.two_blas_scene(0.0, 24) if scene == "two_blas" else scenes.branch_scene()
+        sa = s.arrays()
+        cam = scenes.camera_for(view, Wd, Hd)
+        _SPARSE_CACHE[scene] = (sa, cam) + tuple(Oracle(sa, Wd, Hd, **v).render(cam, 3))
+    sa, cam, ref, seeds, e, c = _SPARSE_CACHE[scene]
+    d = Device(Wd, Hd, **v)
+    d.upload(sa)
+    d.seed_default()
+    d.enable_steps(True)
+    d.render(cam, 3)
+    assert_bits(d.read_accum(), ref, f"{scene}: thin {thin}, xcd rays {xcd}")
+    assert np.array_equal(d.get_seeds(), seeds)
+    _ctr_equal(d.counters(), e, c)
+    d.close()
+
+
 @pytest.mark.parametrize("accel", [0, 1])
 def test_persistent_wavefronts_vs_oracle(accel, monkeypatch):
     """The persistent-wavefront kernels (k_trace_persist / k_trace_persist4) only take over when a queue is longer than one ray per
