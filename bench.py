@@ -177,7 +177,7 @@ def main():
     # Load order decides which HIP runtime the process runs on: torch first = the ROCm 7.0 runtime bundled in the torch wheel, librt355.so
     # first = the system's ROCm 7.2 (the library's RUNPATH).  A single context is 12 % faster on the former (732 against 645 M samples/s,
     # EXPERIMENTS.md (44)); RT355_IMPORT_ORDER=lib-first selects the latter for A/B runs.  Either way librt355.so is loaded before HIP
-    # INITIALISES (importing torch does not initialise it), which is when its request for eight hardware queues has to be in place.
+    # INITIALISES (importing torch does not initialise it), which is when its request for sixteen hardware queues has to be in place.
     from magr_ray_tracer_amd import _lib
     if os.environ.get("RT355_IMPORT_ORDER") != "lib-first":
         import torch

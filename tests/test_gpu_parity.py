@@ -1531,7 +1531,7 @@ def test_contexts_share_one_device_copy_of_the_scene():
 
 
 def test_bench_default_path_four_lanes_one_scene_copy_vs_oracle(tmp_path):
-    """`python bench.py` as the driver runs it (four lanes on eight hardware queues, one shared device copy of the scene, HIP events on
+    """`python bench.py` as the driver runs it (four lanes, the hardware queues requested by the library, one shared device copy of the scene, HIP events on
     lane 0), at a small frame: the bench line carries what BASELINE asks for, and the accumulator it reduced is the sum of the four
     lanes' sample streams as the ORACLE renders them - bit for bit."""
     import json
